@@ -1,0 +1,210 @@
+/* rt_api.h — C ABI of the MI355X render path.
+ *
+ * The reference is a single executable with no plugin/FFI surface; this boundary replaces the span between
+ * its two timer reads (raytracer.cpp:109 and :192): "given the parsed scene, the built BVH and the config,
+ * fill the image".  Everything on the far side of it is hand-written HIP for gfx950.
+ *
+ * Ownership: the caller owns every buffer it passes in; the context copies what it needs during the
+ * rt_upload_* calls.  Nothing returned needs freeing except the context.
+ * Errors: every call returns RT_OK (0) or a negative code and never throws or exits; rt_last_error() gives
+ * the text.  Threading: calls on one context must be serialised by the caller; contexts are independent.
+ */
+#ifndef RT_API_H
+#define RT_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    RT_OK = 0,
+    RT_ERR_ARG = -1,        /* bad argument / inconsistent sizes */
+    RT_ERR_HIP = -2,        /* a HIP runtime call failed (no device, out of memory, launch failure) */
+    RT_ERR_STATE = -3,      /* call order: render before upload, ... */
+    RT_ERR_CAPACITY = -4,   /* workspace too small for the requested depth / sample fan-out */
+    RT_ERR_IO = -5,         /* host surface: file missing / malformed */
+    RT_ERR_PARSE = -6       /* host surface: scene text the reference's scanner would throw on */
+};
+
+/* ---- scene PODs ------------------------------------------------------------------------------------ */
+
+/* Camera fields as Camera::parseCameraDataFromJson leaves them (camera.h:14-22, camera.cpp:68-100):
+ * focal_length and sensor already divided by 1000; aperture = 0 unless depth of field is enabled. */
+typedef struct rt_camera {
+    float location[3];
+    float gaze[3];
+    float aperture;
+    float focal_length;
+    float focal_distance;
+    float sensor_width;
+    float sensor_height;
+    float res_x;
+    float res_y;
+} rt_camera;
+
+/* pointlight.h:11-12 */
+typedef struct rt_light {
+    float location[3];
+    float rad_intensity;
+} rt_light;
+
+/* shape.h:16-24.  tex_id = index into rt_scene.textures, or -1 when the shape's hasTex is false
+ * (texture mapping off, or "texture": null; sphere.cpp:105-109). */
+typedef struct rt_material {
+    float diffuse[3];
+    float specular[3];
+    float shininess;
+    float transparency;
+    float ior;
+    int32_t tex_id;
+} rt_material;
+
+/* sphere.h:14-26 */
+typedef struct rt_sphere {
+    float start[3];
+    float end[3];
+    float radius;
+    rt_material mat;
+} rt_sphere;
+
+/* cube.h:14-30: rotation = XYZ Euler radians, scale = uniform half edge. */
+typedef struct rt_cube {
+    float start[3];
+    float end[3];
+    float rotation[3];
+    float scale;
+    rt_material mat;
+} rt_cube;
+
+/* plane.h:15-37: a planar polygon.  Vertices are in FILE order (the order of "corners" in scene.json, which
+ * is Blender vertex order, not winding order); normal is what Plane::calculateNormal (plane.cpp:304-321)
+ * computed from the first three of them.  The library derives the winding-sorted copy itself. */
+typedef struct rt_plane {
+    int32_t n_verts;
+    int32_t first_vert;      /* index of this plane's first vertex in rt_scene.plane_verts (xyz triples) */
+    float normal[3];
+    rt_material mat;
+} rt_plane;
+
+/* A texture exactly as the reference's PPM reader produced it (image.cpp:13-67), i.e. for a P6 file with
+ * every channel already moved down by one byte.  rgb = height*width*3 ints, row-major, top row first. */
+typedef struct rt_texture {
+    int32_t width;
+    int32_t height;
+    const int32_t* rgb;
+} rt_texture;
+
+typedef struct rt_scene {
+    rt_camera camera;        /* cams[0]; the reference renders only the first camera (raytracer.cpp:107-136) */
+    int32_t n_lights;   const rt_light* lights;
+    int32_t n_spheres;  const rt_sphere* spheres;
+    int32_t n_cubes;    const rt_cube* cubes;
+    int32_t n_planes;   const rt_plane* planes;
+    int32_t n_plane_verts; const float* plane_verts;   /* n_plane_verts * 3 floats */
+    int32_t n_textures; const rt_texture* textures;
+} rt_scene;
+
+/* One node of the host-built pointer BVH (bvh.h:13-37), flattened in any order with the root at index 0.
+ * left/right = child node index or -1.  A node with left == right == -1 is a leaf and owns
+ * prim_ids[first_prim .. first_prim + n_planes + n_cubes + n_spheres): plane indices first, then cube
+ * indices, then sphere indices, each in the order the reference's leaf vectors hold them (bvh.cpp:113-115). */
+typedef struct rt_bvh_node {
+    float box_min[3];
+    float box_max[3];
+    int32_t left;
+    int32_t right;
+    int32_t first_prim;
+    int32_t n_planes;
+    int32_t n_cubes;
+    int32_t n_spheres;
+} rt_bvh_node;
+
+/* ---- render configuration ---------------------------------------------------------------------------- */
+
+/* Every field of struct Config (config.h:8-27) except outputFile, in the same order, then the additions
+ * this implementation needs.  Fill with rt_default_config() first. */
+typedef struct rt_config {
+    int32_t soft_shadows;         /* config.h:8   -ss   */
+    int32_t ss_samples;           /* config.h:9   -sss  */
+    int32_t glossy_reflect;       /* config.h:10  -gr   */
+    int32_t gr_samples;           /* config.h:11  -grs  */
+    float   light_radius;         /* config.h:12        */
+    int32_t anti_aliasing;        /* config.h:14  -aa   */
+    int32_t aa_samples;           /* config.h:15  -aas  */
+    int32_t textures;             /* config.h:17  -t    */
+    int32_t bvh;                  /* config.h:19  -u clears it */
+    int32_t reflect_refract_depth;/* config.h:22  -r / -rd */
+    int32_t dof;                  /* config.h:24  -dof  */
+    int32_t dof_samples;          /* config.h:25  -dofs */
+    int32_t motion_blur;          /* config.h:26  -m    */
+    int32_t mb_samples;           /* config.h:27  -mbs  */
+    /* additions (no counterpart in the reference) */
+    uint32_t seed;                /* key of the counter-based generator; the reference never seeds rand() */
+    int32_t fallback;             /* brute-force retry of secondary rays after a BVH miss (raytracer.cpp:424,484):
+                                     0 = auto (1 when the scene has <= 4096 primitives, else 2),
+                                     1 = over every primitive, exactly as the reference,
+                                     2 = only over primitives that stick out of their leaf box */
+} rt_config;
+
+typedef struct rt_stats {
+    uint64_t primary_rays;        /* camera samples traced */
+    uint64_t shadow_rays;
+    uint64_t reflection_rays;     /* traced; identical copies the reference would re-trace are not counted here */
+    uint64_t refraction_rays;
+    uint64_t reflection_rays_ref; /* what the reference would trace (x gr_samples when glossy is off) */
+    uint64_t nodes_shaded;        /* hits that went through Blinn-Phong */
+    uint64_t batches;             /* pipeline passes (one per sample index per pixel chunk) */
+    double   ms_total;            /* rt_render*: enqueue -> results ready, host wall clock */
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+/* ---- calls ------------------------------------------------------------------------------------------- */
+
+void rt_default_config(rt_config* cfg);
+
+/* Creates a context on HIP device `device_id`.  workspace_bytes = upper bound for the ray queues and the
+ * hit-tree arena (0 = default of 4 GiB); it is allocated lazily by the first render and grown never. */
+rt_ctx* rt_create(int device_id, uint64_t workspace_bytes);
+void rt_destroy(rt_ctx* ctx);
+
+/* Work is enqueued on `hip_stream` (a hipStream_t; NULL = the context's own stream). */
+int rt_set_stream(rt_ctx* ctx, void* hip_stream);
+
+/* Copies the scene to the device (replaces raytracer.cpp:55-59 as the producer of the render loop's inputs). */
+int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene);
+
+/* Copies the host-built BVH (the result of BVHNode::buildBVH, bvh.cpp:108-172) and re-lays it out for the
+ * device.  n_nodes == 0 or nodes == NULL: no BVH (only -u renders are possible). Must follow rt_upload_scene. */
+int rt_upload_bvh(rt_ctx* ctx, const rt_bvh_node* nodes, int32_t n_nodes, const int32_t* prim_ids, int32_t n_prim_ids);
+
+/* Image sharding for one-process-per-GPU runs: this context renders the 32x32-pixel tiles t with
+ * (tile_x + tile_y) % world == rank.  Default rank 0 of world 1 = whole image. */
+int rt_set_shard(rt_ctx* ctx, int32_t rank, int32_t world);
+/* Number of tiles this context renders / the largest count over all ranks (gather buffers are padded to it). */
+int32_t rt_local_tiles(const rt_ctx* ctx);
+int32_t rt_max_tiles_per_rank(const rt_ctx* ctx);
+
+/* The render loop (raytracer.cpp:109-193).  world == 1: rgb_out receives res_y*res_x*3 bytes, row-major,
+ * y down, rgb[y][x][c] = (int)(255*colour) exactly as raytracer.cpp:173-175.  world > 1: rgb_out receives this
+ * rank's tiles, rt_max_tiles_per_rank()*32*32*3 bytes, tile-major (unused tail zeroed).
+ * rt_render copies the result to host memory and waits; rt_render_device leaves it in device memory
+ * (rgb_out_dev is a device pointer) and only enqueues, unless stats != NULL, in which case it also waits. */
+int rt_render(rt_ctx* ctx, const rt_config* cfg, uint8_t* rgb_out, rt_stats* stats);
+int rt_render_device(rt_ctx* ctx, const rt_config* cfg, void* rgb_out_dev, rt_stats* stats);
+
+/* Rank 0 after the gather: tiles_dev = world * rt_max_tiles_per_rank()*32*32*3 bytes (rank-major, each block
+ * as rt_render_device wrote it); rgb_out_dev = res_y*res_x*3 bytes row-major.  Enqueue only. */
+int rt_assemble_tiles(rt_ctx* ctx, const void* tiles_dev, int32_t world, void* rgb_out_dev);
+
+/* Blocks until everything enqueued on the context's stream has finished. */
+int rt_synchronize(rt_ctx* ctx);
+
+const char* rt_last_error(const rt_ctx* ctx);   /* ctx may be NULL: error of the last failed rt_create */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,361 @@
+"""ctypes binding of raytracer_amd/librt_amd.so (include/rt_api.h + include/rt_host.h).
+
+Plumbing only: every call below lands in the C ABI; there is no Python or CPU rendering path.  If the library
+(and therefore the HIP kernels) is missing, importing the binding's `lib()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "librt_amd.so"
+TILE = 32
+
+RT_OK = 0
+
+
+class RtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rt error {code}: {msg}")
+        self.code = code
+
+
+class Camera(C.Structure):
+    _fields_ = [("location", C.c_float * 3), ("gaze", C.c_float * 3), ("aperture", C.c_float),
+                ("focal_length", C.c_float), ("focal_distance", C.c_float), ("sensor_width", C.c_float),
+                ("sensor_height", C.c_float), ("res_x", C.c_float), ("res_y", C.c_float)]
+
+
+class Light(C.Structure):
+    _fields_ = [("location", C.c_float * 3), ("rad_intensity", C.c_float)]
+
+
+class Material(C.Structure):
+    _fields_ = [("diffuse", C.c_float * 3), ("specular", C.c_float * 3), ("shininess", C.c_float),
+                ("transparency", C.c_float), ("ior", C.c_float), ("tex_id", C.c_int32)]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("start", C.c_float * 3), ("end", C.c_float * 3), ("radius", C.c_float), ("mat", Material)]
+
+
+class Cube(C.Structure):
+    _fields_ = [("start", C.c_float * 3), ("end", C.c_float * 3), ("rotation", C.c_float * 3),
+                ("scale", C.c_float), ("mat", Material)]
+
+
+class Plane(C.Structure):
+    _fields_ = [("n_verts", C.c_int32), ("first_vert", C.c_int32), ("normal", C.c_float * 3), ("mat", Material)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgb", C.POINTER(C.c_int32))]
+
+
+class Scene(C.Structure):
+    _fields_ = [("camera", Camera),
+                ("n_lights", C.c_int32), ("lights", C.POINTER(Light)),
+                ("n_spheres", C.c_int32), ("spheres", C.POINTER(Sphere)),
+                ("n_cubes", C.c_int32), ("cubes", C.POINTER(Cube)),
+                ("n_planes", C.c_int32), ("planes", C.POINTER(Plane)),
+                ("n_plane_verts", C.c_int32), ("plane_verts", C.POINTER(C.c_float)),
+                ("n_textures", C.c_int32), ("textures", C.POINTER(Texture))]
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("box_min", C.c_float * 3), ("box_max", C.c_float * 3), ("left", C.c_int32), ("right", C.c_int32),
+                ("first_prim", C.c_int32), ("n_planes", C.c_int32), ("n_cubes", C.c_int32), ("n_spheres", C.c_int32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("soft_shadows", C.c_int32), ("ss_samples", C.c_int32), ("glossy_reflect", C.c_int32),
+                ("gr_samples", C.c_int32), ("light_radius", C.c_float), ("anti_aliasing", C.c_int32),
+                ("aa_samples", C.c_int32), ("textures", C.c_int32), ("bvh", C.c_int32),
+                ("reflect_refract_depth", C.c_int32), ("dof", C.c_int32), ("dof_samples", C.c_int32),
+                ("motion_blur", C.c_int32), ("mb_samples", C.c_int32), ("seed", C.c_uint32), ("fallback", C.c_int32)]
+
+    def samples_per_pixel(self) -> int:
+        return ((self.aa_samples if self.anti_aliasing else 1) * (self.dof_samples if self.dof else 1) *
+                (self.mb_samples if self.motion_blur else 1))
+
+
+class Stats(C.Structure):
+    _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("reflection_rays", C.c_uint64),
+                ("refraction_rays", C.c_uint64), ("reflection_rays_ref", C.c_uint64), ("nodes_shaded", C.c_uint64),
+                ("batches", C.c_uint64), ("ms_total", C.c_double)]
+
+    def total_rays(self) -> int:
+        return self.primary_rays + self.shadow_rays + self.reflection_rays + self.refraction_rays
+
+    def total_rays_ref(self) -> int:
+        return self.primary_rays + self.shadow_rays + self.reflection_rays_ref + self.refraction_rays
+
+
+class HostScene(C.Structure):
+    _fields_ = [("scene", Scene), ("n_cameras", C.c_int32), ("storage", C.c_void_p)]
+
+
+class HostBvh(C.Structure):
+    _fields_ = [("nodes", C.POINTER(BvhNode)), ("n_nodes", C.c_int32), ("prim_ids", C.POINTER(C.c_int32)),
+                ("n_prim_ids", C.c_int32)]
+
+
+# every symbol the two headers declare
+API_SYMBOLS = ["rt_default_config", "rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_upload_bvh",
+               "rt_set_shard", "rt_local_tiles", "rt_max_tiles_per_rank", "rt_render", "rt_render_device",
+               "rt_assemble_tiles", "rt_synchronize", "rt_last_error"]
+HOST_SYMBOLS = ["rt_host_parse_args", "rt_host_parse_scene", "rt_host_load_scene", "rt_host_free_scene",
+                "rt_host_build_bvh", "rt_host_free_bvh", "rt_host_read_ppm", "rt_host_write_ppm", "rt_host_free",
+                "rt_host_camera_ray"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise FileNotFoundError(f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
+                                "(there is no fallback path)")
+    L = C.CDLL(str(LIB_PATH))
+    L.rt_default_config.argtypes = [C.POINTER(Config)]
+    L.rt_create.argtypes = [C.c_int, C.c_uint64]; L.rt_create.restype = C.c_void_p
+    L.rt_destroy.argtypes = [C.c_void_p]; L.rt_destroy.restype = None
+    L.rt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.rt_upload_scene.argtypes = [C.c_void_p, C.POINTER(Scene)]
+    L.rt_upload_bvh.argtypes = [C.c_void_p, C.POINTER(BvhNode), C.c_int32, C.POINTER(C.c_int32), C.c_int32]
+    L.rt_set_shard.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.rt_local_tiles.argtypes = [C.c_void_p]; L.rt_local_tiles.restype = C.c_int32
+    L.rt_max_tiles_per_rank.argtypes = [C.c_void_p]; L.rt_max_tiles_per_rank.restype = C.c_int32
+    L.rt_render.argtypes = [C.c_void_p, C.POINTER(Config), C.c_void_p, C.POINTER(Stats)]
+    L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(Config), C.c_void_p, C.POINTER(Stats)]
+    L.rt_assemble_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.rt_synchronize.argtypes = [C.c_void_p]
+    L.rt_last_error.argtypes = [C.c_void_p]; L.rt_last_error.restype = C.c_char_p
+    L.rt_host_parse_args.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(Config), C.c_char_p, C.c_int]
+    L.rt_host_parse_scene.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Config), C.c_char_p, C.c_int]
+    L.rt_host_parse_scene.restype = C.POINTER(HostScene)
+    L.rt_host_load_scene.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Config), C.c_char_p, C.c_int]
+    L.rt_host_load_scene.restype = C.POINTER(HostScene)
+    L.rt_host_free_scene.argtypes = [C.POINTER(HostScene)]; L.rt_host_free_scene.restype = None
+    L.rt_host_build_bvh.argtypes = [C.POINTER(Scene), C.c_int32, C.POINTER(HostBvh)]
+    L.rt_host_free_bvh.argtypes = [C.POINTER(HostBvh)]; L.rt_host_free_bvh.restype = None
+    L.rt_host_read_ppm.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.POINTER(C.c_int32))]
+    L.rt_host_write_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    L.rt_host_free.argtypes = [C.c_void_p]; L.rt_host_free.restype = None
+    L.rt_host_camera_ray.argtypes = [C.POINTER(Camera), C.c_float, C.c_float, C.POINTER(C.c_float)]
+    L.rt_host_camera_ray.restype = None
+    _lib = L
+    return L
+
+
+# ---- host surface ----------------------------------------------------------------------------------------
+
+def parse_args(flags: list[str], extensions: bool = True) -> tuple[Config, str]:
+    """Config::parseArgs of the reference (config.cpp:7-91) on a flag list (program name not included)."""
+    argv = [b"raytracer"] + [f.encode() for f in flags]
+    arr = (C.c_char_p * len(argv))(*argv)
+    cfg = Config()
+    name = C.create_string_buffer(512)
+    lib().rt_host_parse_args(len(argv), arr, 1 if extensions else 0, C.byref(cfg), name, 512)
+    return cfg, name.value.decode()
+
+
+class LoadedScene:
+    """A parsed scene (rt_host_parse_scene) and, on demand, its host-built BVH (rt_host_build_bvh)."""
+
+    def __init__(self, text: str, cfg: Config, textures_dir: str | None = None):
+        err = C.create_string_buffer(512)
+        self._hs = lib().rt_host_parse_scene(text.encode(), textures_dir.encode() if textures_dir else None,
+                                             C.byref(cfg), err, 512)
+        if not self._hs:
+            raise RtError(-6, err.value.decode())
+        self._bvh = None
+
+    @property
+    def scene(self) -> Scene:
+        return self._hs.contents.scene
+
+    @property
+    def width(self) -> int:
+        return int(self.scene.camera.res_x)
+
+    @property
+    def height(self) -> int:
+        return int(self.scene.camera.res_y)
+
+    def bvh(self, max_depth: int = 8) -> HostBvh:
+        if self._bvh is None:
+            b = HostBvh()
+            rc = lib().rt_host_build_bvh(C.byref(self._hs.contents.scene), max_depth, C.byref(b))
+            if rc != RT_OK:
+                raise RtError(rc, "rt_host_build_bvh failed")
+            self._bvh = b
+        return self._bvh
+
+    def bvh_nodes(self) -> np.ndarray:
+        """Pre-order dump comparable with the oracle's orc_bvh_dump: min3, max3, has_left, has_right, np, nc, ns."""
+        b = self.bvh()
+        out = np.zeros((b.n_nodes, 11), dtype=np.float32)
+        for i in range(b.n_nodes):
+            n = b.nodes[i]
+            out[i, 0:3] = list(n.box_min); out[i, 3:6] = list(n.box_max)
+            out[i, 6] = 1.0 if n.left >= 0 else 0.0; out[i, 7] = 1.0 if n.right >= 0 else 0.0
+            out[i, 8] = n.n_planes; out[i, 9] = n.n_cubes; out[i, 10] = n.n_spheres
+        return out
+
+    def close(self):
+        if self._bvh is not None:
+            lib().rt_host_free_bvh(C.byref(self._bvh)); self._bvh = None
+        if self._hs:
+            lib().rt_host_free_scene(self._hs); self._hs = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def camera_ray(cam: Camera, x: float, y: float) -> np.ndarray:
+    out = (C.c_float * 6)()
+    lib().rt_host_camera_ray(C.byref(cam), x, y, out)
+    return np.array(list(out), dtype=np.float32)
+
+
+def read_ppm(path: str) -> np.ndarray:
+    w, h, m = C.c_int32(), C.c_int32(), C.c_int32()
+    p = C.POINTER(C.c_int32)()
+    rc = lib().rt_host_read_ppm(path.encode(), C.byref(w), C.byref(h), C.byref(m), C.byref(p))
+    if rc != RT_OK:
+        raise RtError(rc, f"cannot read {path}")
+    arr = np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
+    lib().rt_host_free(p)
+    return arr
+
+
+def write_ppm(path: str, img: np.ndarray, maxval: int = 255) -> None:
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    rc = lib().rt_host_write_ppm(path.encode(), img.shape[1], img.shape[0], maxval, img.ctypes.data_as(C.c_void_p))
+    if rc != RT_OK:
+        raise RtError(rc, f"cannot write {path}")
+
+
+# ---- render boundary -------------------------------------------------------------------------------------
+
+class Renderer:
+    """One rt_ctx on one GPU."""
+
+    def __init__(self, device: int = 0, workspace_bytes: int = 0):
+        self._ctx = lib().rt_create(device, workspace_bytes)
+        if not self._ctx:
+            raise RtError(-2, lib().rt_last_error(None).decode())
+        self.width = self.height = 0
+        self.rank, self.world = 0, 1
+
+    def _check(self, rc: int):
+        if rc != RT_OK:
+            raise RtError(rc, lib().rt_last_error(self._ctx).decode())
+
+    def set_stream(self, stream_handle: int | None):
+        self._check(lib().rt_set_stream(self._ctx, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def upload(self, ls: LoadedScene, with_bvh: bool = True):
+        self._check(lib().rt_upload_scene(self._ctx, C.byref(ls.scene)))
+        self.width, self.height = ls.width, ls.height
+        if with_bvh:
+            b = ls.bvh()
+            self._check(lib().rt_upload_bvh(self._ctx, b.nodes, b.n_nodes, b.prim_ids, b.n_prim_ids))
+        else:
+            self._check(lib().rt_upload_bvh(self._ctx, None, 0, None, 0))
+
+    def set_shard(self, rank: int, world: int):
+        self._check(lib().rt_set_shard(self._ctx, rank, world))
+        self.rank, self.world = rank, world
+
+    @property
+    def local_tiles(self) -> int:
+        return lib().rt_local_tiles(self._ctx)
+
+    @property
+    def max_tiles_per_rank(self) -> int:
+        return lib().rt_max_tiles_per_rank(self._ctx)
+
+    def out_bytes(self) -> int:
+        if self.world > 1:
+            return self.max_tiles_per_rank * TILE * TILE * 3
+        return self.width * self.height * 3
+
+    def render(self, cfg: Config) -> tuple[np.ndarray, Stats]:
+        """rt_render: result copied to host. world == 1 -> [H,W,3] uint8; else the flat tile-major block."""
+        out = np.zeros(self.out_bytes(), dtype=np.uint8)
+        st = Stats()
+        self._check(lib().rt_render(self._ctx, C.byref(cfg), out.ctypes.data_as(C.c_void_p), C.byref(st)))
+        if self.world == 1:
+            out = out.reshape(self.height, self.width, 3)
+        return out, st
+
+    def render_device(self, cfg: Config, out_ptr: int, want_stats: bool = False) -> Stats | None:
+        st = Stats() if want_stats else None
+        self._check(lib().rt_render_device(self._ctx, C.byref(cfg), C.c_void_p(out_ptr), C.byref(st) if st else None))
+        return st
+
+    def assemble(self, tiles_ptr: int, world: int, out_ptr: int):
+        self._check(lib().rt_assemble_tiles(self._ctx, C.c_void_p(tiles_ptr), world, C.c_void_p(out_ptr)))
+
+    def synchronize(self):
+        self._check(lib().rt_synchronize(self._ctx))
+
+    def close(self):
+        if self._ctx:
+            lib().rt_destroy(self._ctx); self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def render_scene_text(text: str, flags: list[str], textures_dir: str | None = None, device: int = 0,
+                      workspace_bytes: int = 0):
+    """Convenience used by tests and smoke(): parse flags + scene, build the BVH on the host, render on the GPU."""
+    cfg, _ = parse_args(flags)
+    ls = LoadedScene(text, cfg, textures_dir)
+    r = Renderer(device, workspace_bytes)
+    try:
+        r.upload(ls, with_bvh=bool(cfg.bvh))
+        img, st = r.render(cfg)
+    finally:
+        r.close(); ls.close()
+    return img, st
+
+
+def tile_owner_slots(width: int, height: int, world: int):
+    """For tests: (owner rank, index inside that rank's block) per tile, matching rt_set_shard's rule."""
+    tx_n, ty_n = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+    counts = [0] * world
+    out = {}
+    for ty in range(ty_n):
+        for tx in range(tx_n):
+            o = (tx + ty) % world
+            out[(tx, ty)] = (o, counts[o]); counts[o] += 1
+    return out, max(counts), tx_n, ty_n
+
+
+def assemble_tiles_numpy(blocks: list[np.ndarray], width: int, height: int) -> np.ndarray:
+    """Host-side equivalent of rt_assemble_tiles for tests: blocks[r] = rank r's flat tile-major bytes."""
+    world = len(blocks)
+    slots, max_tiles, tx_n, ty_n = tile_owner_slots(width, height, world)
+    img = np.zeros((height, width, 3), dtype=np.uint8)
+    for (tx, ty), (o, k) in slots.items():
+        t = blocks[o][k * TILE * TILE * 3:(k + 1) * TILE * TILE * 3].reshape(TILE, TILE, 3)
+        y0, x0 = ty * TILE, tx * TILE
+        hh, ww = min(TILE, height - y0), min(TILE, width - x0)
+        img[y0:y0 + hh, x0:x0 + ww] = t[:hh, :ww]
+    return img

@@ -1,0 +1,603 @@
+// Context behind the C ABI of include/rt_api.h: device copies of the scene, the re-laid-out BVH, the work
+// buffers, and the per-frame launch sequence.  All device work goes through the kernels in rt_kernels.hip.
+#include "rt_api.h"
+#include "rt_types.h"
+#include "camera_basis.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_create_error;
+
+template <class T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    hipError_t resize(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        release();
+        size_t c = std::max<size_t>(count, 1);
+        hipError_t e = hipMalloc((void**)&p, c * sizeof(T));
+        if (e == hipSuccess) n = c; else p = nullptr;
+        return e;
+    }
+    hipError_t upload(const std::vector<T>& v, hipStream_t s) {
+        hipError_t e = resize(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+};
+
+inline float4 f4(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
+inline float as_f(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+inline float smaxh(float a, float b) { return (a < b) ? b : a; }
+inline float sminh(float a, float b) { return (b < a) ? b : a; }
+
+// plane.cpp:207-216
+int drop_axis(const float n[3]) {
+    float nx = std::fabs(n[0]), ny = std::fabs(n[1]), nz = std::fabs(n[2]);
+    if (nx > ny && nx > nz) return 0;
+    if (ny > nz) return 1;
+    return 2;
+}
+
+// Plane::sortVerticesWinding, plane.cpp:254-301: order by atan2 of the offset from the centroid in the plane's
+// dominant 2D projection.  std::sort on <= 16 elements is an insertion sort, which a stable sort reproduces.
+std::vector<int> winding_order(const float* v, int n, const float normal[3]) {
+    float c[3] = { 0.0f, 0.0f, 0.0f };
+    for (int i = 0; i < n; ++i) { c[0] += v[3 * i]; c[1] += v[3 * i + 1]; c[2] += v[3 * i + 2]; }
+    float fn = (float)(size_t)n;
+    c[0] /= fn; c[1] /= fn; c[2] /= fn;
+    int drop = drop_axis(normal);
+    int a0 = (drop == 0) ? 1 : 0, a1 = (drop == 2) ? 1 : 2;
+    std::vector<float> ang((size_t)n);
+    for (int i = 0; i < n; ++i) ang[i] = std::atan2(v[3 * i + a1] - c[a1], v[3 * i + a0] - c[a0]);
+    std::vector<int> idx((size_t)n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return ang[a] < ang[b]; });
+    return idx;
+}
+
+float len_ref(const float v[3]) {
+    return (float)std::sqrt((double)v[0] * (double)v[0] + (double)v[1] * (double)v[1] + (double)v[2] * (double)v[2]);
+}
+
+} // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    uint64_t workspace_limit = 0;
+    std::string err;
+
+    // host copy of what the BVH upload needs
+    bool have_scene = false, have_bvh = false;
+    rt_camera camera{};
+    std::vector<rt_sphere> spheres; std::vector<rt_cube> cubes; std::vector<rt_plane> planes;
+    std::vector<float> plane_verts;          // file order
+    std::vector<float4> h_verts_sorted;      // device layout, indexed by first_vert + k
+    std::vector<float4> h_file_planes, h_file_cubes, h_file_spheres;
+    int n_lights = 0;
+    bool any_reflective = false, any_transparent = false;
+
+    // device scene
+    DevBuf<float4> d_nodes, d_mats, d_plane_uv, d_texels, d_lights, d_verts;
+    DevBuf<int4> d_leaves, d_tex_desc;
+    DevBuf<float4> d_file_planes, d_file_cubes, d_file_spheres, d_leaf_planes, d_leaf_cubes, d_leaf_spheres;
+    DevScene scene{};
+
+    // sharding
+    int rank = 0, world = 1;
+    int tiles_x = 0, tiles_y = 0, max_tiles = 0;
+    std::vector<int> local_tiles;
+    DevBuf<int> d_local_tiles;
+
+    // work buffers
+    DevBuf<float4> q_a[2], q_b[2], n_a, n_b, n_c, n_col, accum;
+    DevBuf<float2> n_uv;
+    DevBuf<int> n_pix, link, ctr;
+    DevBuf<float> shadow;
+    DevBuf<unsigned long long> stats;
+    DevBuf<unsigned char> out_tmp;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        err = buf; return code;
+    }
+    int hip(hipError_t e, const char* what) {
+        if (e == hipSuccess) return RT_OK;
+        return fail(RT_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    }
+    void rebuild_tiles() {
+        int W = (int)camera.res_x, H = (int)camera.res_y;
+        tiles_x = (W + RT_TILE - 1) / RT_TILE; tiles_y = (H + RT_TILE - 1) / RT_TILE;
+        local_tiles.clear();
+        std::vector<int> per_rank((size_t)world, 0);
+        for (int ty = 0; ty < tiles_y; ++ty)
+            for (int tx = 0; tx < tiles_x; ++tx) {
+                int owner = (tx + ty) % world;
+                per_rank[owner]++;
+                if (owner == rank) local_tiles.push_back(ty * tiles_x + tx);
+            }
+        max_tiles = 0;
+        for (int c : per_rank) max_tiles = std::max(max_tiles, c);
+    }
+};
+
+#define RT_TRY(expr) do { int rc__ = (expr); if (rc__ != RT_OK) return rc__; } while (0)
+#define RT_HIP(ctx, call) RT_TRY((ctx)->hip((call), #call))
+
+extern "C" {
+
+rt_ctx* rt_create(int device_id, uint64_t workspace_bytes) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_create_error = std::string("no HIP device: ") + hipGetErrorString(e); return nullptr; }
+    if (device_id < 0 || device_id >= n) { g_create_error = "device id out of range"; return nullptr; }
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
+    rt_ctx* c = new rt_ctx();
+    c->device = device_id;
+    c->workspace_limit = workspace_bytes ? workspace_bytes : (4ull << 30);
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return nullptr; }
+    c->stream = c->own_stream;
+    return c;
+}
+
+void rt_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf<float4>* f4s[] = { &c->d_nodes, &c->d_mats, &c->d_plane_uv, &c->d_texels, &c->d_lights, &c->d_verts, &c->d_file_planes,
+                              &c->d_file_cubes, &c->d_file_spheres, &c->d_leaf_planes, &c->d_leaf_cubes, &c->d_leaf_spheres,
+                              &c->q_a[0], &c->q_a[1], &c->q_b[0], &c->q_b[1], &c->n_a, &c->n_b, &c->n_c, &c->n_col, &c->accum };
+    for (auto* b : f4s) b->release();
+    c->d_leaves.release(); c->d_tex_desc.release(); c->d_local_tiles.release(); c->n_uv.release(); c->n_pix.release();
+    c->link.release(); c->ctr.release(); c->shadow.release(); c->stats.release(); c->out_tmp.release();
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int rt_set_stream(rt_ctx* c, void* hip_stream) {
+    if (!c) return RT_ERR_ARG;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return RT_OK;
+}
+
+const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int rt_synchronize(rt_ctx* c) {
+    if (!c) return RT_ERR_ARG;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
+    if (!c || !sc) return RT_ERR_ARG;
+    if (sc->n_lights < 0 || sc->n_spheres < 0 || sc->n_cubes < 0 || sc->n_planes < 0 || sc->n_textures < 0)
+        return c->fail(RT_ERR_ARG, "negative count in scene");
+    if ((sc->n_lights && !sc->lights) || (sc->n_spheres && !sc->spheres) || (sc->n_cubes && !sc->cubes) ||
+        (sc->n_planes && (!sc->planes || !sc->plane_verts)) || (sc->n_textures && !sc->textures))
+        return c->fail(RT_ERR_ARG, "null array with non-zero count in scene");
+    if (!(sc->camera.res_x >= 1.0f && sc->camera.res_y >= 1.0f && sc->camera.res_x <= 65536.0f && sc->camera.res_y <= 65536.0f))
+        return c->fail(RT_ERR_ARG, "film resolution out of range");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));     // previous frames may still read the old arrays
+
+    c->camera = sc->camera;
+    c->spheres.assign(sc->spheres, sc->spheres + sc->n_spheres);
+    c->cubes.assign(sc->cubes, sc->cubes + sc->n_cubes);
+    c->planes.assign(sc->planes, sc->planes + sc->n_planes);
+    c->plane_verts.assign(sc->plane_verts, sc->plane_verts + (size_t)sc->n_plane_verts * 3);
+    c->n_lights = sc->n_lights;
+    c->have_bvh = false;
+
+    const int np = sc->n_planes, nc = sc->n_cubes, ns = sc->n_spheres;
+    std::vector<float4> mats((size_t)(np + nc + ns) * 3);
+    c->any_reflective = c->any_transparent = false;
+    auto put_mat = [&](int gid, const rt_material& m) -> int {
+        if (m.tex_id >= sc->n_textures) return RT_ERR_ARG;
+        // raytracer.cpp:374-375: mean specular times 0.5 (the 0.5 is a double literal; the product is exact), clamped
+        float refl = (float)((double)((m.specular[0] + m.specular[1] + m.specular[2]) / 3.0f) * 0.5);
+        refl = sminh(smaxh(refl, 0.0f), 1.0f);
+        mats[(size_t)gid * 3 + 0] = f4(m.diffuse[0], m.diffuse[1], m.diffuse[2], m.shininess);
+        mats[(size_t)gid * 3 + 1] = f4(m.specular[0], m.specular[1], m.specular[2], m.transparency);
+        mats[(size_t)gid * 3 + 2] = f4(m.ior, as_f(m.tex_id < 0 ? -1 : m.tex_id), refl, 0.0f);
+        if (refl > 0) c->any_reflective = true;
+        if (m.transparency > 0) c->any_transparent = true;
+        return RT_OK;
+    };
+
+    // planes: winding-sorted vertices, projection axis, texture axes
+    c->h_verts_sorted.assign((size_t)sc->n_plane_verts, f4(0, 0, 0, 0));
+    c->h_file_planes.assign((size_t)np * 3, f4(0, 0, 0, 0));
+    std::vector<float4> plane_uv((size_t)np * 3, f4(0, 0, 0, 0));
+    for (int i = 0; i < np; ++i) {
+        const rt_plane& p = sc->planes[i];
+        if (p.n_verts < 3 || p.n_verts > 0xffff || p.first_vert < 0 || p.first_vert + p.n_verts > sc->n_plane_verts)
+            return c->fail(RT_ERR_ARG, "plane %d: vertex range out of bounds", i);
+        const float* v = sc->plane_verts + (size_t)p.first_vert * 3;
+        std::vector<int> ord = winding_order(v, p.n_verts, p.normal);
+        for (int k = 0; k < p.n_verts; ++k)
+            c->h_verts_sorted[(size_t)p.first_vert + k] = f4(v[3 * ord[k]], v[3 * ord[k] + 1], v[3 * ord[k] + 2], 0.0f);
+        const float4 s0 = c->h_verts_sorted[(size_t)p.first_vert];
+        const float4 s1 = c->h_verts_sorted[(size_t)p.first_vert + 1];
+        const float4 sl = c->h_verts_sorted[(size_t)p.first_vert + p.n_verts - 1];
+        int packed = p.n_verts | (drop_axis(p.normal) << 16);
+        // File-order set = the objects in the reference's own vectors, which Plane::intersect sorts in place on
+        // first use (plane.cpp:158), so the plane offset is taken from the first SORTED vertex there.
+        c->h_file_planes[(size_t)i * 3 + 0] = f4(p.normal[0], p.normal[1], p.normal[2], as_f(p.first_vert));
+        c->h_file_planes[(size_t)i * 3 + 1] = f4(s0.x, s0.y, s0.z, as_f(packed));
+        c->h_file_planes[(size_t)i * 3 + 2] = f4(as_f(i), 0, 0, 0);
+        // plane.cpp:164-170
+        float us[3] = { s1.x - s0.x, s1.y - s0.y, s1.z - s0.z }, vs[3] = { sl.x - s0.x, sl.y - s0.y, sl.z - s0.z };
+        float ul = len_ref(us), vl = len_ref(vs);
+        rt_normalise_ref(us); rt_normalise_ref(vs);
+        plane_uv[(size_t)i * 3 + 0] = f4(us[0], us[1], us[2], ul);
+        plane_uv[(size_t)i * 3 + 1] = f4(vs[0], vs[1], vs[2], vl);
+        plane_uv[(size_t)i * 3 + 2] = f4(s0.x, s0.y, s0.z, 0.0f);
+        if (put_mat(i, p.mat) != RT_OK) return c->fail(RT_ERR_ARG, "plane %d: texture id out of range", i);
+    }
+    // cubes: rotation sines/cosines from the host libm, exactly the values cube.cpp:301-313 and :328-346 compute per ray
+    c->h_file_cubes.assign((size_t)nc * 6, f4(0, 0, 0, 0));
+    for (int i = 0; i < nc; ++i) {
+        const rt_cube& q = sc->cubes[i];
+        float ix = -q.rotation[0], iy = -q.rotation[1], iz = -q.rotation[2];
+        float4* w = &c->h_file_cubes[(size_t)i * 6];
+        w[0] = f4(q.start[0], q.start[1], q.start[2], q.scale);
+        w[1] = f4(q.end[0], q.end[1], q.end[2], 1.0f / q.scale);
+        w[2] = f4(std::cos(q.rotation[0]), std::sin(q.rotation[0]), std::cos(q.rotation[1]), std::sin(q.rotation[1]));
+        w[3] = f4(std::cos(q.rotation[2]), std::sin(q.rotation[2]), as_f(np + i), 0.0f);
+        w[4] = f4(std::cos(iz), std::sin(iz), std::cos(iy), std::sin(iy));
+        w[5] = f4(std::cos(ix), std::sin(ix), 0.0f, 0.0f);
+        if (put_mat(np + i, q.mat) != RT_OK) return c->fail(RT_ERR_ARG, "cube %d: texture id out of range", i);
+    }
+    c->h_file_spheres.assign((size_t)ns * 2, f4(0, 0, 0, 0));
+    for (int i = 0; i < ns; ++i) {
+        const rt_sphere& s = sc->spheres[i];
+        c->h_file_spheres[(size_t)i * 2 + 0] = f4(s.start[0], s.start[1], s.start[2], s.radius);
+        c->h_file_spheres[(size_t)i * 2 + 1] = f4(s.end[0], s.end[1], s.end[2], as_f(np + nc + i));
+        if (put_mat(np + nc + i, s.mat) != RT_OK) return c->fail(RT_ERR_ARG, "sphere %d: texture id out of range", i);
+    }
+    std::vector<float4> lights((size_t)sc->n_lights);
+    for (int i = 0; i < sc->n_lights; ++i)
+        lights[i] = f4(sc->lights[i].location[0], sc->lights[i].location[1], sc->lights[i].location[2], sc->lights[i].rad_intensity);
+    // textures: value / 255.0f as raytracer.cpp:294-296 computes per lookup
+    std::vector<int4> tex_desc((size_t)sc->n_textures);
+    std::vector<float4> texels;
+    for (int t = 0; t < sc->n_textures; ++t) {
+        const rt_texture& tx = sc->textures[t];
+        if (tx.width < 1 || tx.height < 1 || !tx.rgb) return c->fail(RT_ERR_ARG, "texture %d: bad size or null data", t);
+        tex_desc[t] = make_int4(tx.width, tx.height, (int)texels.size(), 0);
+        size_t n = (size_t)tx.width * tx.height;
+        size_t base = texels.size();
+        texels.resize(base + n);
+        for (size_t k = 0; k < n; ++k)
+            texels[base + k] = f4(tx.rgb[3 * k] / 255.0f, tx.rgb[3 * k + 1] / 255.0f, tx.rgb[3 * k + 2] / 255.0f, 0.0f);
+    }
+
+    hipStream_t s = c->stream;
+    RT_HIP(c, c->d_mats.upload(mats, s));
+    RT_HIP(c, c->d_plane_uv.upload(plane_uv, s));
+    RT_HIP(c, c->d_verts.upload(c->h_verts_sorted, s));
+    RT_HIP(c, c->d_file_planes.upload(c->h_file_planes, s));
+    RT_HIP(c, c->d_file_cubes.upload(c->h_file_cubes, s));
+    RT_HIP(c, c->d_file_spheres.upload(c->h_file_spheres, s));
+    RT_HIP(c, c->d_lights.upload(lights, s));
+    RT_HIP(c, c->d_tex_desc.upload(tex_desc, s));
+    RT_HIP(c, c->d_texels.upload(texels, s));
+    RT_HIP(c, hipStreamSynchronize(s));             // the host vectors above die with this scope
+
+    DevScene& d = c->scene;
+    std::memset(&d, 0, sizeof d);
+    d.fileset.planes = c->d_file_planes.p; d.fileset.verts = c->d_verts.p; d.fileset.cubes = c->d_file_cubes.p;
+    d.fileset.spheres = c->d_file_spheres.p; d.fileset.n_planes = np; d.fileset.n_cubes = nc; d.fileset.n_spheres = ns;
+    d.leafset = d.fileset;
+    d.mats = c->d_mats.p; d.plane_uv = c->d_plane_uv.p; d.tex_desc = c->d_tex_desc.p; d.texels = c->d_texels.p;
+    d.lights = c->d_lights.p; d.n_lights = sc->n_lights;
+    c->have_scene = true;
+    c->rebuild_tiles();
+    RT_HIP(c, c->d_local_tiles.upload(c->local_tiles, s));
+    RT_HIP(c, hipStreamSynchronize(s));
+    return RT_OK;
+}
+
+int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const int32_t* prim_ids, int32_t n_prim_ids) {
+    if (!c) return RT_ERR_ARG;
+    if (!c->have_scene) return c->fail(RT_ERR_STATE, "rt_upload_bvh before rt_upload_scene");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->have_bvh = false;
+    if (!nodes || n_nodes <= 0) return RT_OK;
+    if (n_prim_ids < 0 || (n_prim_ids && !prim_ids)) return c->fail(RT_ERR_ARG, "bad prim_ids");
+    const int np = (int)c->planes.size(), nc = (int)c->cubes.size(), ns = (int)c->spheres.size();
+
+    // Re-lay the pointer tree out for a stackless walk.  The reference's traversal keeps the hit of the last leaf
+    // (in left-to-right depth-first order) that has one, so the device visits right children first and stops at the
+    // first leaf with a hit; nodes are stored in exactly that visiting order, each with the index to continue at
+    // when its subtree is skipped.  A node with a single child has the same primitive set, hence bit-identical
+    // box, as that child (AABB::fromPoints over the same objects): such chains are folded into one test.
+    struct Out { float mn[3], mx[3]; int skip, leaf; };
+    std::vector<Out> out; std::vector<int4> leaves;
+    std::vector<float4> lp, lc, ls;
+    std::vector<char> seen((size_t)n_nodes, 0);
+    std::string problem;
+    // iterative pre-order, right child first
+    struct Item { int node; int phase; int out_idx; };
+    std::vector<Item> st; st.push_back({ 0, 0, -1 });
+    while (!st.empty()) {
+        Item it = st.back(); st.pop_back();
+        if (it.phase == 1) { out[(size_t)it.out_idx].skip = (int)out.size(); continue; }
+        int ni = it.node;
+        if (ni < 0 || ni >= n_nodes) { problem = "child index out of range"; break; }
+        if (seen[(size_t)ni]) { problem = "node reachable twice"; break; }
+        seen[(size_t)ni] = 1;
+        // fold single-child chains with identical boxes
+        for (;;) {
+            const rt_bvh_node& n = nodes[ni];
+            int only = (n.left >= 0 && n.right < 0) ? n.left : ((n.right >= 0 && n.left < 0) ? n.right : -1);
+            if (only < 0 || only >= n_nodes) break;
+            if (std::memcmp(n.box_min, nodes[only].box_min, 12) != 0 || std::memcmp(n.box_max, nodes[only].box_max, 12) != 0) break;
+            if (seen[(size_t)only]) { problem = "node reachable twice"; break; }
+            seen[(size_t)only] = 1; ni = only;
+        }
+        if (!problem.empty()) break;
+        const rt_bvh_node& n = nodes[ni];
+        Out o{}; std::memcpy(o.mn, n.box_min, 12); std::memcpy(o.mx, n.box_max, 12); o.skip = 0; o.leaf = -1;
+        int my = (int)out.size();
+        if (n.left < 0 && n.right < 0) {
+            int cnt = n.n_planes + n.n_cubes + n.n_spheres;
+            if (n.n_planes < 0 || n.n_cubes < 0 || n.n_spheres < 0 || n.first_prim < 0 || n.first_prim + cnt > n_prim_ids) { problem = "leaf range out of bounds"; break; }
+            o.leaf = (int)(leaves.size() / 2);
+            leaves.push_back(make_int4((int)(lp.size() / 3), n.n_planes, (int)(lc.size() / 6), n.n_cubes));
+            leaves.push_back(make_int4((int)(ls.size() / 2), n.n_spheres, 0, 0));
+            const int32_t* ids = prim_ids + n.first_prim;
+            for (int k = 0; k < n.n_planes; ++k) {
+                int id = ids[k]; if (id < 0 || id >= np) { problem = "plane id out of range"; break; }
+                const rt_plane& p = c->planes[(size_t)id];
+                const float* v0 = &c->plane_verts[(size_t)p.first_vert * 3];
+                // Leaves hold copies made before any ray was traced (bvh.cpp:113, :70): the plane offset comes
+                // from the first vertex in FILE order.
+                lp.push_back(c->h_file_planes[(size_t)id * 3 + 0]);
+                float4 w1 = c->h_file_planes[(size_t)id * 3 + 1];
+                lp.push_back(f4(v0[0], v0[1], v0[2], w1.w));
+                lp.push_back(c->h_file_planes[(size_t)id * 3 + 2]);
+            }
+            for (int k = 0; k < n.n_cubes && problem.empty(); ++k) {
+                int id = ids[n.n_planes + k]; if (id < 0 || id >= nc) { problem = "cube id out of range"; break; }
+                for (int q = 0; q < 6; ++q) lc.push_back(c->h_file_cubes[(size_t)id * 6 + q]);
+            }
+            for (int k = 0; k < n.n_spheres && problem.empty(); ++k) {
+                int id = ids[n.n_planes + n.n_cubes + k]; if (id < 0 || id >= ns) { problem = "sphere id out of range"; break; }
+                for (int q = 0; q < 2; ++q) ls.push_back(c->h_file_spheres[(size_t)id * 2 + q]);
+            }
+            if (!problem.empty()) break;
+            out.push_back(o);
+            out[(size_t)my].skip = my + 1;
+        } else {
+            out.push_back(o);
+            st.push_back({ ni, 1, my });                     // runs after both subtrees: fixes skip
+            if (n.left >= 0) st.push_back({ n.left, 0, -1 });  // popped second
+            if (n.right >= 0) st.push_back({ n.right, 0, -1 }); // popped first
+        }
+    }
+    if (!problem.empty()) return c->fail(RT_ERR_ARG, "rt_upload_bvh: %s", problem.c_str());
+    if (out.size() > RT_MAX_LDS_NODES || leaves.size() / 2 > RT_MAX_LDS_LEAVES)
+        return c->fail(RT_ERR_CAPACITY, "BVH has %zu nodes / %zu leaves after folding; at most %d / %d fit the on-chip copy",
+                       out.size(), leaves.size() / 2, RT_MAX_LDS_NODES, RT_MAX_LDS_LEAVES);
+
+    std::vector<float4> dn(out.size() * 2);
+    for (size_t i = 0; i < out.size(); ++i) {
+        dn[2 * i] = f4(out[i].mn[0], out[i].mn[1], out[i].mn[2], as_f(out[i].skip));
+        dn[2 * i + 1] = f4(out[i].mx[0], out[i].mx[1], out[i].mx[2], as_f(out[i].leaf));
+    }
+    hipStream_t s = c->stream;
+    RT_HIP(c, c->d_nodes.upload(dn, s));
+    RT_HIP(c, c->d_leaves.upload(leaves, s));
+    RT_HIP(c, c->d_leaf_planes.upload(lp, s));
+    RT_HIP(c, c->d_leaf_cubes.upload(lc, s));
+    RT_HIP(c, c->d_leaf_spheres.upload(ls, s));
+    RT_HIP(c, hipStreamSynchronize(s));
+    DevScene& d = c->scene;
+    d.nodes = c->d_nodes.p; d.n_nodes = (int)out.size();
+    d.leaves = c->d_leaves.p; d.n_leaves = (int)(leaves.size() / 2);
+    d.leafset.planes = c->d_leaf_planes.p; d.leafset.verts = c->d_verts.p; d.leafset.cubes = c->d_leaf_cubes.p;
+    d.leafset.spheres = c->d_leaf_spheres.p;
+    d.leafset.n_planes = (int)(lp.size() / 3); d.leafset.n_cubes = (int)(lc.size() / 6); d.leafset.n_spheres = (int)(ls.size() / 2);
+    c->have_bvh = true;
+    return RT_OK;
+}
+
+int rt_set_shard(rt_ctx* c, int32_t rank, int32_t world) {
+    if (!c) return RT_ERR_ARG;
+    if (world < 1 || rank < 0 || rank >= world) return c->fail(RT_ERR_ARG, "rank %d of world %d", rank, world);
+    c->rank = rank; c->world = world;
+    if (c->have_scene) {
+        RT_HIP(c, hipSetDevice(c->device));
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+        c->rebuild_tiles();
+        RT_HIP(c, c->d_local_tiles.upload(c->local_tiles, c->stream));
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return RT_OK;
+}
+
+int32_t rt_local_tiles(const rt_ctx* c) { return c ? (int32_t)c->local_tiles.size() : 0; }
+int32_t rt_max_tiles_per_rank(const rt_ctx* c) { return c ? c->max_tiles : 0; }
+
+// Enqueue one frame.  out_dev: device buffer in the layout rt_render_device documents.
+static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev, bool want_stats_zero) {
+    if (!c->have_scene) return c->fail(RT_ERR_STATE, "render before rt_upload_scene");
+    if (cfg->bvh && !c->have_bvh) return c->fail(RT_ERR_STATE, "config asks for the BVH but none was uploaded");
+    const int AA = cfg->anti_aliasing ? cfg->aa_samples : 1;
+    const int DOF = cfg->dof ? cfg->dof_samples : 1;
+    const int MB = cfg->motion_blur ? cfg->mb_samples : 1;
+    if (AA < 1 || DOF < 1 || MB < 1) return c->fail(RT_ERR_ARG, "sample counts must be >= 1");
+    if ((long long)AA * DOF * MB > (1ll << 30)) return c->fail(RT_ERR_ARG, "too many samples per pixel");
+    if (cfg->gr_samples < 1 || cfg->gr_samples >= (1 << 30)) return c->fail(RT_ERR_ARG, "gr_samples must be >= 1");
+    if (cfg->soft_shadows && cfg->ss_samples < 1) return c->fail(RT_ERR_ARG, "ss_samples must be >= 1");
+    const int D = cfg->reflect_refract_depth < 0 ? 0 : cfg->reflect_refract_depth;
+    if (D > RT_MAX_LEVELS - 4) return c->fail(RT_ERR_ARG, "reflect depth above %d", RT_MAX_LEVELS - 4);
+    const int S = AA * DOF * MB;
+    const int L = c->n_lights;
+    const int n_prims = (int)(c->planes.size() + c->cubes.size() + c->spheres.size());
+
+    DevFrame f; std::memset(&f, 0, sizeof f);
+    rt_camera_basis cb = rt_make_camera_basis(c->camera);
+    for (int i = 0; i < 3; ++i) { f.cam_loc[i] = c->camera.location[i]; f.fwd[i] = cb.fwd[i]; f.right[i] = cb.right[i]; f.up[i] = cb.up[i]; }
+    f.sw_over_fl = cb.sw_over_fl; f.sh_over_fl = cb.sh_over_fl; f.res_x = c->camera.res_x; f.res_y = c->camera.res_y;
+    f.lens_radius = cb.lens_radius; f.focal_distance = c->camera.focal_distance;
+    f.width = (int)c->camera.res_x; f.height = (int)c->camera.res_y;
+    f.soft_shadows = cfg->soft_shadows != 0; f.ss_samples = cfg->ss_samples; f.glossy = cfg->glossy_reflect != 0; f.gr_samples = cfg->gr_samples;
+    f.anti_aliasing = cfg->anti_aliasing != 0; f.aa_n = AA; f.dof_on = cfg->dof != 0; f.dof_n = DOF; f.mb_on = cfg->motion_blur != 0; f.mb_n = MB;
+    f.textures = cfg->textures != 0; f.use_bvh = cfg->bvh != 0; f.motion_blur = cfg->motion_blur != 0; f.max_depth = D;
+    int fb = cfg->fallback; if (fb == 0) fb = (n_prims <= 4096) ? 1 : 2;
+    f.fallback_full = (fb == 1);
+    f.light_radius = cfg->light_radius; f.seed = cfg->seed;
+    f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y; f.n_local_tiles = (int)c->local_tiles.size(); f.local_tiles = c->d_local_tiles.p;
+
+    const long long n_slots = (long long)c->local_tiles.size() * RT_TILE_PIX;
+    // Worst-case fan-out per hit: every hit reflects (gr_samples rays when glossy, one otherwise) and refracts.
+    const long long k_refl = c->any_reflective ? (cfg->glossy_reflect ? cfg->gr_samples : 1) : 0;
+    const long long k = D > 0 ? k_refl + (c->any_transparent ? 1 : 0) : 0;
+    // per primary sample: nodes = sum_{d<=D} k^d, links = sum_{1<=d<=D} k^d, widest level = k^D (or 1)
+    double nodes_per = 0, widest = 1, pw = 1;
+    for (int d = 0; d <= D; ++d) { nodes_per += pw; widest = std::max(widest, pw); pw *= (double)k; if (k == 0) break; }
+    double links_per = nodes_per - 1.0;
+    const bool grouped = !cfg->soft_shadows || (cfg->ss_samples <= 64 && (cfg->ss_samples & (cfg->ss_samples - 1)) == 0);
+    double bytes_per = nodes_per * (16.0 * 4 + (f.textures ? 8 : 0) + 4.0 * std::max(L, 1)) + 4.0 + links_per * 4.0 +
+                       (k > 0 ? 2.0 * widest * 32.0 : 0.0);
+    long long B = (long long)((double)c->workspace_limit / bytes_per);
+    B = std::min(B, n_slots);
+    // int32 indexing inside the kernels
+    B = std::min(B, (long long)(2.0e9 / std::max(1.0, nodes_per * std::max(1, L) * (cfg->soft_shadows ? cfg->ss_samples : 1))));
+    if (B >= RT_TILE_PIX) B -= B % RT_TILE_PIX; else B -= B % 64;
+    if (B < 64) return c->fail(RT_ERR_CAPACITY, "workspace of %llu bytes cannot hold one wavefront of samples at depth %d with fan-out %lld",
+                               (unsigned long long)c->workspace_limit, D, k);
+    const size_t cap_nodes = (size_t)((double)B * nodes_per) + 64;
+    const size_t cap_links = (size_t)((double)B * links_per) + 64;
+    const size_t cap_rays = k > 0 ? (size_t)((double)B * widest) + 64 : 64;
+
+    hipStream_t s = c->stream;
+    RT_HIP(c, hipSetDevice(c->device));
+    const bool grow = cap_nodes > c->n_a.n || cap_links > c->link.n || cap_rays > c->q_a[0].n || (size_t)n_slots > c->accum.n ||
+                      (f.textures && cap_nodes > c->n_uv.n) || cap_nodes * (size_t)std::max(L, 1) > c->shadow.n || (size_t)B > c->n_pix.n;
+    if (grow) RT_HIP(c, hipStreamSynchronize(s));
+    for (int q = 0; q < 2; ++q) { RT_HIP(c, c->q_a[q].resize(cap_rays)); RT_HIP(c, c->q_b[q].resize(cap_rays)); }
+    RT_HIP(c, c->n_a.resize(cap_nodes)); RT_HIP(c, c->n_b.resize(cap_nodes)); RT_HIP(c, c->n_c.resize(cap_nodes));
+    RT_HIP(c, c->n_col.resize(cap_nodes));
+    if (f.textures) RT_HIP(c, c->n_uv.resize(cap_nodes));
+    RT_HIP(c, c->n_pix.resize((size_t)B));
+    RT_HIP(c, c->shadow.resize(cap_nodes * (size_t)std::max(L, 1)));
+    RT_HIP(c, c->link.resize(cap_links));
+    RT_HIP(c, c->accum.resize((size_t)n_slots));
+    RT_HIP(c, c->ctr.resize(RT_C_TOTAL));
+    RT_HIP(c, c->stats.resize(RT_S_TOTAL));
+
+    DevWork w; std::memset(&w, 0, sizeof w);
+    for (int q = 0; q < 2; ++q) { w.q_a[q] = c->q_a[q].p; w.q_b[q] = c->q_b[q].p; }
+    w.n_a = c->n_a.p; w.n_b = c->n_b.p; w.n_c = c->n_c.p; w.n_uv = c->n_uv.p; w.n_col = c->n_col.p; w.n_pix = c->n_pix.p;
+    w.shadow = c->shadow.p; w.link = c->link.p; w.accum = c->accum.p; w.ctr = c->ctr.p; w.stats = c->stats.p;
+    w.cap_nodes = (unsigned)std::min<size_t>(cap_nodes, 0x7fffffffu);
+    w.cap_rays = (unsigned)std::min<size_t>(cap_rays, 0x7fffffffu);
+    w.cap_links = (unsigned)std::min<size_t>(cap_links, 0x7fffffffu);
+
+    RT_HIP(c, hipMemsetAsync(c->accum.p, 0, (size_t)n_slots * sizeof(float4), s));
+    RT_HIP(c, hipMemsetAsync(c->ctr.p, 0, RT_C_TOTAL * sizeof(int), s));
+    if (want_stats_zero) RT_HIP(c, hipMemsetAsync(c->stats.p, 0, RT_S_TOTAL * sizeof(unsigned long long), s));
+
+    const int max_grid = 2048;       // 256 CUs x 8 workgroups: enough to fill the chip, grid-stride beyond that
+    unsigned long long batches = 0;
+    for (long long begin = 0; begin < n_slots; begin += B) {
+        const int count = (int)std::min<long long>(B, n_slots - begin);
+        f.pix_begin = (int)begin; f.pix_count = count;
+        const int grid0 = std::max(1, std::min(max_grid, (count + RT_BLOCK - 1) / RT_BLOCK));
+        for (int smp = 0; smp < S; ++smp) {
+            f.sample = smp;
+            RT_HIP(c, hipMemsetAsync(c->ctr.p, 0, 2 * sizeof(int), s));     // RT_C_NODE, RT_C_LINK
+            for (int level = 0; level <= D; ++level) {
+                rt_launch_level_begin(s, w, level);
+                rt_launch_extend(s, c->scene, f, w, level, level == 0 ? grid0 : max_grid);
+            }
+            rt_launch_level_begin(s, w, D + 1);
+            if (!grouped) RT_HIP(c, hipMemsetAsync(c->shadow.p, 0, cap_nodes * (size_t)std::max(L, 1) * sizeof(float), s));
+            if (L > 0) rt_launch_shadow(s, c->scene, f, w, max_grid);
+            for (int level = D; level >= 0; --level) rt_launch_shade(s, c->scene, f, w, level, level == 0 ? grid0 : max_grid);
+            ++batches;
+        }
+    }
+    const int tile_major = c->world > 1;
+    if (tile_major) {
+        size_t total = (size_t)c->max_tiles * RT_TILE_PIX * 3, used = (size_t)n_slots * 3;
+        if (total > used) RT_HIP(c, hipMemsetAsync(out_dev + used, 0, total - used, s));
+    }
+    rt_launch_finalize(s, f, w, out_dev, tile_major, (int)n_slots, S);
+    RT_HIP(c, hipGetLastError());
+    c->err.clear();
+    (void)batches;
+    return RT_OK;
+}
+
+static int finish_stats(rt_ctx* c, rt_stats* st, double ms, unsigned long long batches_hint) {
+    int ctr[4] = { 0, 0, 0, 0 };
+    unsigned long long hs[RT_S_TOTAL];
+    RT_HIP(c, hipMemcpyAsync(ctr, c->ctr.p, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipMemcpyAsync(hs, c->stats.p, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (st) {
+        st->primary_rays = hs[RT_S_PRIMARY]; st->shadow_rays = hs[RT_S_SHADOW]; st->reflection_rays = hs[RT_S_REFLECT];
+        st->refraction_rays = hs[RT_S_REFRACT]; st->reflection_rays_ref = hs[RT_S_REFLECT_REF]; st->nodes_shaded = hs[RT_S_NODES];
+        st->batches = batches_hint; st->ms_total = ms;
+    }
+    if (ctr[RT_C_ERR]) return c->fail(RT_ERR_CAPACITY, "a work buffer overflowed during the frame; the image is incomplete");
+    return RT_OK;
+}
+
+int rt_render_device(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev, rt_stats* stats) {
+    if (!c || !cfg || !rgb_out_dev) return RT_ERR_ARG;
+    auto t0 = std::chrono::steady_clock::now();
+    RT_TRY(enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true));
+    if (!stats) return RT_OK;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return finish_stats(c, stats, ms, 0);
+}
+
+int rt_render(rt_ctx* c, const rt_config* cfg, uint8_t* rgb_out, rt_stats* stats) {
+    if (!c || !cfg || !rgb_out) return RT_ERR_ARG;
+    if (!c->have_scene) return c->fail(RT_ERR_STATE, "render before rt_upload_scene");
+    RT_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = c->world > 1 ? (size_t)c->max_tiles * RT_TILE_PIX * 3
+                                      : (size_t)((int)c->camera.res_x) * (size_t)((int)c->camera.res_y) * 3;
+    if (bytes > c->out_tmp.n) { RT_HIP(c, hipStreamSynchronize(c->stream)); RT_HIP(c, c->out_tmp.resize(bytes)); }
+    auto t0 = std::chrono::steady_clock::now();
+    RT_TRY(enqueue_frame(c, cfg, c->out_tmp.p, true));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    RT_HIP(c, hipMemcpy(rgb_out, c->out_tmp.p, bytes, hipMemcpyDeviceToHost));
+    return finish_stats(c, stats, ms, 0);
+}
+
+int rt_assemble_tiles(rt_ctx* c, const void* tiles_dev, int32_t world, void* rgb_out_dev) {
+    if (!c || !tiles_dev || !rgb_out_dev || world < 1) return RT_ERR_ARG;
+    if (!c->have_scene) return c->fail(RT_ERR_STATE, "assemble before rt_upload_scene");
+    if (world != c->world) return c->fail(RT_ERR_ARG, "world %d differs from the context's shard setting %d", world, c->world);
+    RT_HIP(c, hipSetDevice(c->device));
+    rt_launch_assemble(c->stream, (const unsigned char*)tiles_dev, world, c->max_tiles, c->tiles_x, c->tiles_y,
+                       (int)c->camera.res_x, (int)c->camera.res_y, (unsigned char*)rgb_out_dev);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,850 @@
+// gfx950 kernels of the render path: extend (primary-ray generation fused in at level 0), shadow, shade/resolve,
+// finalize, tile assembly.  One lane per ray / per hit; 64-lane wavefronts; work items are compacted in HBM
+// queues between kernels so that every launched lane has work.
+//
+// Arithmetic contract (build with -ffp-contract=off, IEEE divide/sqrt): every expression keeps the operand
+// types and the association the reference's C++ has, so that discrete decisions (which primitive is hit,
+// whether a slab test passes, int(255*c)) agree with it.  Reference citations are relative to its Code/ dir.
+#include "rt_types.h"
+
+#include <float.h>
+#include <math.h>
+
+#define DEVI __device__ __forceinline__
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------------
+DEVI float smax(float a, float b) { return (a < b) ? b : a; }        // std::max: NaN in `a` survives
+DEVI float smin(float a, float b) { return (b < a) ? b : a; }        // std::min
+DEVI int f2i(float f) { return __float_as_int(f); }
+DEVI float i2f(int i) { return __int_as_float(i); }
+
+struct V3 { float x, y, z; };
+DEVI V3 mk(float x, float y, float z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
+DEVI V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEVI V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEVI V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+DEVI float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                    // raytracer.cpp:588-592
+DEVI V3 cross(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// raytracer.cpp:577-585: squares and their sum in double, double sqrt, length rounded to float, float divides
+DEVI float len_ref(V3 v) { return (float)sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z); }
+DEVI V3 normalise(V3 v) { float l = len_ref(v); return mk(v.x / l, v.y / l, v.z / l); }
+DEVI float lerp_ref(float a, float b, float t) { return a + t * (b - a); }                   // raytracer.cpp:671-673
+// std::pow(float,float) of the reference is glibc powf; a double-precision pow rounded once to float agrees
+// with it except where powf itself is not correctly rounded.
+DEVI float powf_ref(float x, float y) { return (float)pow((double)x, (double)y); }
+
+struct Ray { V3 o, d; float time; };
+
+// Philox-4x32-10 counter-based generator: value = f(counter, key), no state, any lane can draw any number.
+DEVI uint4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0, hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+DEVI float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }               // [0,1)
+DEVI uint32_t mix32(uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
+enum { STREAM_AA = 1, STREAM_DOF = 2, STREAM_MB = 3, STREAM_SHADOW = 4, STREAM_GLOSSY = 5 };
+
+// raytracer.cpp:634-644 on three uniforms
+DEVI V3 unit_sphere(float u, float v, float w) {
+    float theta = (float)((double)(u * 2.0f) * M_PI);
+    float phi = acosf(2.0f * v - 1.0f);
+    float r = cbrtf(w);
+    return mk(r * sinf(phi) * cosf(theta), r * sinf(phi) * sinf(theta), r * cosf(phi));
+}
+
+// raytracer.cpp:647-668: z and phi come from 1000-level quantised draws; basis from (0,1,0) x dir
+DEVI V3 cone_direction(V3 dir, float angle, uint32_t r0, uint32_t r1) {
+    float cosTheta = cosf(angle);
+    float z = cosTheta + (1.0f - cosTheta) * ((float)(int)((r0 >> 1) % 1000u) / 1000.0f);
+    float phi = (float)((double)(2.0f) * M_PI * (double)((float)(int)((r1 >> 1) % 1000u) / 1000.0f));
+    float r = sqrtf(1.0f - z * z);
+    V3 rv = mk(r * cosf(phi), r * sinf(phi), z);
+    V3 u = normalise(cross(mk(0.0f, 1.0f, 0.0f), dir));
+    V3 v = cross(dir, u);
+    V3 s = mk(rv.x * u.x + rv.y * v.x + rv.z * dir.x, rv.x * u.y + rv.y * v.y + rv.z * dir.y, rv.x * u.z + rv.y * v.z + rv.z * dir.z);
+    return normalise(s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// primitive tests.  Each returns whether the primitive's intersect() would return true and, if so, the
+// rayDistance it would report.  FULL additionally produces the HitStructure fields the shader needs.
+// ---------------------------------------------------------------------------------------------------------
+struct HitOut { V3 p, n; float u, v; int gid; };
+
+// sphere.cpp:118-174
+template <bool FULL>
+DEVI bool sphere_test(const float4* __restrict__ rec, const Ray& r, bool mb, bool want_uv, float& t_out, HitOut* h) {
+    float4 w0 = rec[0], w1 = rec[1];
+    V3 loc = mk(w0.x, w0.y, w0.z);
+    if (mb) loc = mk(lerp_ref(w0.x, w1.x, r.time), lerp_ref(w0.y, w1.y, r.time), lerp_ref(w0.z, w1.z, r.time));
+    float radius = w0.w;
+    V3 l = loc - r.o;
+    float tca = l.x * r.d.x + l.y * r.d.y + l.z * r.d.z;
+    if (tca < 0) return false;
+    float d2 = l.x * l.x + l.y * l.y + l.z * l.z - tca * tca;
+    if (d2 > radius * radius) return false;
+    float thc = sqrtf(radius * radius - d2);
+    float t0 = tca - thc, t1 = tca + thc;
+    float t = (t0 > 0) ? t0 : t1;
+    if (t < 0) return false;
+    t_out = t;
+    if (FULL) {
+        V3 ip = mk(r.o.x + t * r.d.x, r.o.y + t * r.d.y, r.o.z + t * r.d.z);
+        h->p = ip;
+        h->n = mk((ip.x - loc.x) / radius, (ip.y - loc.y) / radius, (ip.z - loc.z) / radius);
+        h->gid = f2i(w1.w);
+        if (want_uv) {                                                   // sphere.cpp:152-162
+            V3 nn = normalise(ip - loc);
+            h->u = (float)((double)0.5f + (double)atan2f(nn.z, nn.x) / (2 * M_PI));
+            h->v = (float)((double)0.5f - (double)asinf(nn.y) / M_PI);
+        }
+    }
+    return true;
+}
+
+// cube.cpp:297-318 with the sines/cosines taken from the record (computed on the host)
+DEVI V3 rot_fwd(V3 v, float4 w2, float4 w3) {
+    float cx = w2.x, sx = w2.y, cy = w2.z, sy = w2.w, cz = w3.x, sz = w3.y;
+    float y1 = v.y * cx - v.z * sx, z1 = v.y * sx + v.z * cx;
+    float x2 = v.x * cy + z1 * sy, z2 = -v.x * sy + z1 * cy;
+    return mk(x2 * cz - y1 * sz, x2 * sz + y1 * cz, z2);
+}
+// cube.cpp:320-351
+DEVI V3 rot_inv(V3 v, float4 w4, float4 w5) {
+    float cz = w4.x, sz = w4.y, cy = w4.z, sy = w4.w, cx = w5.x, sx = w5.y;
+    float x1 = v.x * cz - v.y * sz, y1 = v.x * sz + v.y * cz;
+    float x2 = x1 * cy + v.z * sy, z2 = -x1 * sy + v.z * cy;
+    return mk(x2, y1 * cx - z2 * sx, y1 * sx + z2 * cx);
+}
+
+// cube.cpp:126-292
+template <bool FULL>
+DEVI bool cube_test(const float4* __restrict__ rec, const Ray& r, bool mb, bool want_uv, float& t_out, HitOut* h) {
+    float4 w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3], w4 = rec[4], w5 = rec[5];
+    V3 loc = mk(w0.x, w0.y, w0.z);
+    if (mb) loc = mk(lerp_ref(w0.x, w1.x, r.time), lerp_ref(w0.y, w1.y, r.time), lerp_ref(w0.z, w1.z, r.time));
+    float scale = w0.w, inv = w1.w;
+    V3 o = rot_inv(r.o - loc, w4, w5);
+    V3 d = rot_inv(r.d, w4, w5);
+    V3 lo = o * inv;
+    V3 ld = normalise(d * inv);
+    float tmin = -INFINITY, tmax = INFINITY;
+    {
+        float lov[3] = { lo.x, lo.y, lo.z }, ldv[3] = { ld.x, ld.y, ld.z };
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (fabsf(ldv[i]) < 1e-5f) {
+                if (lov[i] < -1.0f || lov[i] > 1.0f) return false;
+            } else {
+                float t1 = (-1.0f - lov[i]) / ldv[i];
+                float t2 = (1.0f - lov[i]) / ldv[i];
+                if (t1 > t2) { float tt = t1; t1 = t2; t2 = tt; }
+                tmin = smax(tmin, t1);
+                tmax = smin(tmax, t2);
+                if (tmin > tmax) return false;
+            }
+        }
+    }
+    const float T_EPS = 1e-4f;
+    float t = -1.0f;
+    if (tmin > T_EPS) t = tmin; else if (tmax > T_EPS) t = tmax;
+    if (t < 0.0f) return false;
+    V3 hl = mk(lo.x + ld.x * t, lo.y + ld.y * t, lo.z + ld.z * t);
+    V3 hw = rot_fwd(hl * scale, w2, w3) + loc;
+    float worldT = dot(hw - r.o, r.d);
+    worldT = smax(worldT, 1e-4f);
+    t_out = worldT;
+    if (FULL) {
+        const float eps = 1e-5f;
+        float ax = fabsf(hl.x), ay = fabsf(hl.y), az = fabsf(hl.z);
+        V3 nl = mk(0.0f, 0.0f, 0.0f);
+        if (ax >= ay - eps && ax >= az - eps) nl.x = (hl.x > 0) ? 1.0f : -1.0f;
+        else if (ay >= ax - eps && ay >= az - eps) nl.y = (hl.y > 0) ? 1.0f : -1.0f;
+        else nl.z = (hl.z > 0) ? 1.0f : -1.0f;
+        h->p = hw;
+        h->n = normalise(rot_fwd(nl, w2, w3));
+        h->gid = f2i(w3.z);
+        if (want_uv) {                                                   // cube.cpp:197-263
+            float u, v;
+            float maxA = smax(ax, smax(ay, az));
+            if (ax >= maxA - eps) {
+                if (hl.x > 0.0f) { u = (hl.z + 1.0f) * 0.5f; v = (hl.y + 1.0f) * 0.5f; }
+                else { u = (1.0f - hl.z) * 0.5f; v = (hl.y + 1.0f) * 0.5f; }
+            } else if (ay >= maxA - eps) {
+                if (hl.y > 0.0f) { u = (hl.x + 1.0f) * 0.5f; v = (hl.z + 1.0f) * 0.5f; }
+                else { u = (hl.x + 1.0f) * 0.5f; v = (1.0f - hl.z) * 0.5f; }
+            } else {
+                if (hl.z > 0.0f) { u = (hl.x + 1.0f) * 0.5f; v = (hl.y + 1.0f) * 0.5f; }
+                else { u = (1.0f - hl.x) * 0.5f; v = (hl.y + 1.0f) * 0.5f; }
+            }
+            u = fmodf(u, 1.0f); v = fmodf(v, 1.0f);
+            if (u < 0.0f) u += 1.0f;
+            if (v < 0.0f) v += 1.0f;
+            if (u < 0.0f) u = 0.0f;
+            if (u > 1.0f) u = 1.0f;
+            if (v < 0.0f) v = 0.0f;
+            if (v > 1.0f) v = 1.0f;
+            h->u = u; h->v = v;
+        }
+    }
+    return true;
+}
+
+// plane.cpp:143-251.  The polygon's vertices were winding-sorted once on the host (the reference re-sorts them
+// on every call with the same result); the vertex used for the plane offset is the one stored in the record.
+template <bool FULL>
+DEVI bool plane_test(const float4* __restrict__ rec, const float4* __restrict__ verts, const float4* __restrict__ plane_uv,
+                     const Ray& r, bool want_uv, float& t_out, HitOut* h) {
+    float4 w0 = rec[0], w1 = rec[1];
+    float denom = w0.x * r.d.x + w0.y * r.d.y + w0.z * r.d.z;
+    if ((double)fabsf(denom) < 1e-10) return false;
+    float t = (w0.x * (w1.x - r.o.x) + w0.y * (w1.y - r.o.y) + w0.z * (w1.z - r.o.z)) / denom;
+    if (t < 0) return false;
+    V3 ip = mk(r.o.x + t * r.d.x, r.o.y + t * r.d.y, r.o.z + t * r.d.z);
+    int first = f2i(w0.w), packed = f2i(w1.w);
+    int n = packed & 0xffff, drop = packed >> 16;
+    // plane.cpp:205-251: even-odd crossing test in the projection that drops the dominant normal axis
+    float Px = (drop == 0) ? ip.y : ip.x;
+    float Py = (drop == 2) ? ip.y : ip.z;
+    bool inside = false;
+    float4 vj = verts[first + n - 1];
+    for (int i = 0; i < n; ++i) {
+        float4 vi = verts[first + i];
+        float Pix = (drop == 0) ? vi.y : vi.x, Piy = (drop == 2) ? vi.y : vi.z;
+        float Pjx = (drop == 0) ? vj.y : vj.x, Pjy = (drop == 2) ? vj.y : vj.z;
+        vj = vi;
+        if (fabsf(Pjy - Piy) < 1e-8f) continue;
+        if ((Piy > Py) != (Pjy > Py)) {
+            float slope = (Pjx - Pix) / (Pjy - Piy);
+            float xi = slope * (Py - Piy) + Pix;
+            if (Px < xi) inside = !inside;
+        }
+    }
+    if (!inside) return false;
+    t_out = t;
+    if (FULL) {
+        h->p = ip;
+        h->n = mk(w0.x, w0.y, w0.z);
+        int gid = f2i(rec[2].x);
+        h->gid = gid;
+        if (want_uv) {                                                   // plane.cpp:163-184 (axes and lengths from the host)
+            float4 ua = plane_uv[3 * gid], va = plane_uv[3 * gid + 1], s0 = plane_uv[3 * gid + 2];
+            V3 local = ip - mk(s0.x, s0.y, s0.z);
+            float u = dot(local, mk(ua.x, ua.y, ua.z)) / ua.w;
+            float v = dot(local, mk(va.x, va.y, va.z)) / va.w;
+            h->u = fmodf(smax(u, 0.0f), 1.0f);
+            h->v = fmodf(smax(v, 0.0f), 1.0f);
+        }
+    }
+    return true;
+}
+
+// aabb.cpp:31-63: true divisions, ">= 0" picks the near/far plane (so -0.0 takes the positive branch), and the
+// incoming range is ignored.
+DEVI bool slab(const Ray& r, float4 a, float4 b) {
+    float tminx, tmaxx, tminy, tmaxy, tminz, tmaxz;
+    if (r.d.x >= 0) { tminx = (a.x - r.o.x) / r.d.x; tmaxx = (b.x - r.o.x) / r.d.x; }
+    else            { tminx = (b.x - r.o.x) / r.d.x; tmaxx = (a.x - r.o.x) / r.d.x; }
+    if (r.d.y >= 0) { tminy = (a.y - r.o.y) / r.d.y; tmaxy = (b.y - r.o.y) / r.d.y; }
+    else            { tminy = (b.y - r.o.y) / r.d.y; tmaxy = (a.y - r.o.y) / r.d.y; }
+    if (r.d.z >= 0) { tminz = (a.z - r.o.z) / r.d.z; tmaxz = (b.z - r.o.z) / r.d.z; }
+    else            { tminz = (b.z - r.o.z) / r.d.z; tmaxz = (a.z - r.o.z) / r.d.z; }
+    float tMin = smax(tminx, smax(tminy, tminz));
+    float tMax = smin(tmaxx, smin(tmaxy, tmaxz));
+    return tMin <= tMax;
+}
+
+// Result of a trace: class 0 plane / 1 cube / 2 sphere, index inside the set, which set it came from.
+struct Best { float t; int cls; int idx; int fileset; };
+
+// Closest hit over ranges of one primitive set, planes then cubes then spheres, strict '<' (first wins ties).
+// leaf_rule: bvh.cpp:65-95 (start at +inf, require rayDistance >= 0); otherwise raytracer.cpp:202-247 (start at FLT_MAX).
+template <bool ANY>
+DEVI bool test_prims(const DevPrimSet& S, const Ray& r, bool mb, int p0, int pn, int c0, int cn, int s0, int sn,
+                     bool leaf_rule, Best& best) {
+    float closest = leaf_rule ? INFINITY : FLT_MAX;
+    bool hit = false;
+    for (int i = p0; i < p0 + pn; ++i) {
+        float t;
+        if (plane_test<false>(S.planes + 3 * i, S.verts, nullptr, r, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
+            hit = true; closest = t; best.t = t; best.cls = 0; best.idx = i;
+            if (ANY) return true;
+        }
+    }
+    for (int i = c0; i < c0 + cn; ++i) {
+        float t;
+        if (cube_test<false>(S.cubes + 6 * i, r, mb, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
+            hit = true; closest = t; best.t = t; best.cls = 1; best.idx = i;
+            if (ANY) return true;
+        }
+    }
+    for (int i = s0; i < s0 + sn; ++i) {
+        float t;
+        if (sphere_test<false>(S.spheres + 2 * i, r, mb, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
+            hit = true; closest = t; best.t = t; best.cls = 2; best.idx = i;
+            if (ANY) return true;
+        }
+    }
+    return hit;
+}
+
+// BVHNode::intersect (bvh.cpp:35-105) or Raytracer::unacceleratedIntersection (raytracer.cpp:202-256).
+// The reference visits both children of every node whose box is hit and keeps the LAST leaf hit it pushed;
+// walking the nodes right child first and stopping at the first leaf that yields a hit gives the same answer.
+// The node array is laid out in that order with skip links, so the walk needs no stack.
+// with_fallback: raytracer.cpp:424,484 - a secondary ray that misses the BVH is retried over every primitive.
+template <bool ANY>
+DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict__ nodes, const int4* __restrict__ leaves,
+                const Ray& r, bool with_fallback, Best& best) {
+    const bool mb = f.motion_blur != 0;
+    if (f.use_bvh) {
+        int i = 0;
+        const int n = sc.n_nodes;
+        while (i < n) {
+            float4 a = nodes[2 * i], b = nodes[2 * i + 1];
+            if (!slab(r, a, b)) { i = f2i(a.w); continue; }
+            int leaf = f2i(b.w);
+            ++i;
+            if (leaf >= 0) {
+                int4 l0 = leaves[2 * leaf], l1 = leaves[2 * leaf + 1];
+                if (test_prims<ANY>(sc.leafset, r, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, true, best)) { best.fileset = 0; return true; }
+            }
+        }
+        if (!with_fallback) return false;
+        best.fileset = 1;
+        return test_prims<false>(sc.fileset, r, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres, false, best);
+    }
+    best.fileset = 1;
+    return test_prims<ANY>(sc.fileset, r, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres, false, best);
+}
+
+DEVI void full_hit(const DevScene& sc, const DevFrame& f, const Ray& r, const Best& best, HitOut& h) {
+    const DevPrimSet& S = best.fileset ? sc.fileset : sc.leafset;
+    const bool mb = f.motion_blur != 0;
+    float t;
+    h.u = 0.0f; h.v = 0.0f;
+    if (best.cls == 0) {
+        int gid = f2i(S.planes[3 * best.idx + 2].x);
+        bool uv = f.textures && f2i(sc.mats[3 * gid + 2].y) >= 0;
+        plane_test<true>(S.planes + 3 * best.idx, S.verts, sc.plane_uv, r, uv, t, &h);
+    } else if (best.cls == 1) {
+        int gid = f2i(S.cubes[6 * best.idx + 3].z);
+        bool uv = f.textures && f2i(sc.mats[3 * gid + 2].y) >= 0;
+        cube_test<true>(S.cubes + 6 * best.idx, r, mb, uv, t, &h);
+    } else {
+        int gid = f2i(S.spheres[2 * best.idx + 1].w);
+        bool uv = f.textures && f2i(sc.mats[3 * gid + 2].y) >= 0;
+        sphere_test<true>(S.spheres + 2 * best.idx, r, mb, uv, t, &h);
+    }
+}
+
+// Copy the BVH nodes and leaf records into LDS with coalesced 16-byte loads (one pass per workgroup).
+DEVI void stage_bvh(const DevScene& sc, float4* s_nodes, int4* s_leaves) {
+    for (int i = threadIdx.x; i < 2 * sc.n_nodes; i += blockDim.x) s_nodes[i] = sc.nodes[i];
+    for (int i = threadIdx.x; i < 2 * sc.n_leaves; i += blockDim.x) s_leaves[i] = sc.leaves[i];
+    __syncthreads();
+}
+
+// Every lane asks for n consecutive slots (n may be 0); one atomic per wavefront.  Must be reached by all 64 lanes.
+DEVI int wave_alloc(int* counter, int n) {
+    const int lane = __lane_id();
+    int incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+    int total = __shfl(incl, 63, 64);
+    int base = 0;
+    if (lane == 63 && total > 0) base = atomicAdd(counter, total);
+    base = __shfl(base, 63, 64);
+    return base + incl - n;
+}
+
+// Sum a per-thread count over the workgroup and add it to a 64-bit statistic with one atomic.
+DEVI void block_stat_add(unsigned long long* stat, unsigned v, unsigned* s_tmp) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (unsigned k = 0; k < (blockDim.x >> 6); ++k) t += s_tmp[k];
+        if (t) atomicAdd(stat, t);
+    }
+}
+
+// Camera::convertPixelToRay (camera.cpp:109-199) and the sample loops around it (raytracer.cpp:120-141).
+// i = index inside the batch; one batch = one sample index for a range of this rank's pixel slots.
+DEVI bool generate_primary(const DevFrame& f, int i, Ray& r, uint32_t& path, int& slot) {
+    slot = f.pix_begin + i;
+    int tile_local = slot / RT_TILE_PIX, in = slot % RT_TILE_PIX;
+    int gt = f.local_tiles[tile_local];
+    int x = (gt % f.tiles_x) * RT_TILE + (in % RT_TILE);
+    int y = (gt / f.tiles_x) * RT_TILE + (in / RT_TILE);
+    if (x >= f.width || y >= f.height) return false;
+    uint32_t pixel = (uint32_t)(y * f.width + x);
+    int s = f.sample;
+    int s_mb = s % f.mb_n, s_dof = (s / f.mb_n) % f.dof_n, s_aa = s / (f.mb_n * f.dof_n);
+    float u = (float)x, v = (float)y;
+    if (f.anti_aliasing) {                                              // raytracer.cpp:123-127
+        uint4 q = philox(pixel, (uint32_t)s_aa, 0u, STREAM_AA, f.seed, 0x52541u);
+        u = (float)x + u01(q.x);
+        v = (float)y + u01(q.y);
+    }
+    float un = (u + 0.5f) / f.res_x;
+    float vn = (v + 0.5f) / f.res_y;
+    float cam_x = -(un - 0.5f) * f.sw_over_fl;
+    float cam_y = (0.5f - vn) * f.sh_over_fl;
+    float cam_z = -1.0f;
+    V3 d = mk(cam_x * f.right[0] + cam_y * f.up[0] + cam_z * f.fwd[0],
+              cam_x * f.right[1] + cam_y * f.up[1] + cam_z * f.fwd[1],
+              cam_x * f.right[2] + cam_y * f.up[2] + cam_z * f.fwd[2]);
+    float dlen = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+    if (dlen < 1e-6f) d = mk(0.0f, 0.0f, 1.0f);
+    d = normalise(d);
+    d = mk(-d.x, -d.y, -d.z);
+    V3 o = mk(f.cam_loc[0], f.cam_loc[1], f.cam_loc[2]);
+    if (f.lens_radius > 0.0f) {                                         // camera.cpp:181-196, 286-312
+        uint4 q = philox(pixel, (uint32_t)(s_aa * f.dof_n + s_dof), 0u, STREAM_DOF, f.seed, 0x52541u);
+        float lx = 2.0f * u01(q.x) - 1.0f, ly = 2.0f * u01(q.y) - 1.0f;
+        float sx = 0.0f, sy = 0.0f;
+        if (!(lx == 0.0f && ly == 0.0f)) {
+            float theta, rr;
+            if (fabsf(lx) > fabsf(ly)) { rr = lx; theta = (float)((M_PI / 4.0) * (double)(ly / lx)); }
+            else { rr = ly; theta = (float)((M_PI / 2.0) - (M_PI / 4.0) * (double)(lx / ly)); }
+            sx = rr * cosf(theta); sy = rr * sinf(theta);
+        }
+        sx *= f.lens_radius; sy *= f.lens_radius;
+        V3 right = mk(f.right[0], f.right[1], f.right[2]), up = mk(f.up[0], f.up[1], f.up[2]);
+        V3 lens = right * sx + up * sy;
+        V3 focus = o + d * f.focal_distance;
+        o = o + lens;
+        d = normalise(focus - o);
+    }
+    float time = 0.0f;
+    if (f.motion_blur) {                                                // raytracer.cpp:141 (only read when -m is on)
+        uint4 q = philox(pixel, (uint32_t)s, 0u, STREAM_MB, f.seed, 0x52541u);
+        time = ((float)s_mb + u01(q.x)) / (float)f.mb_n;
+    }
+    r.o = o; r.d = d; r.time = time;
+    path = mix32(pixel * 0x9E3779B1u ^ mix32((uint32_t)s * 0x85EBCA6Bu + f.seed));
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// level bookkeeping: one thread between two extend launches
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_level_begin(DevWork w, int level) {
+    int nodes = w.ctr[RT_C_NODE], links = w.ctr[RT_C_LINK];
+    w.ctr[RT_C_NODE_START + level] = nodes;
+    w.ctr[RT_C_LINK_START + level + 1] = links;
+    if (level == 0) w.ctr[RT_C_LINK_START] = 0;
+    else w.ctr[RT_C_RAY_COUNT + level] = links - w.ctr[RT_C_LINK_START + level];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// extend: trace one ray per lane to the hit the reference would report, append a hit-tree node, and spawn the
+// reflection / refraction rays of the next level (raytracer.cpp:144-164 for primaries, :373-498 for the spawn).
+// ---------------------------------------------------------------------------------------------------------
+template <bool PRIMARY>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, DevFrame f, DevWork w, int level) {
+    extern __shared__ float4 s_mem[];
+    float4* s_nodes = s_mem;
+    int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
+    __shared__ unsigned s_tmp[RT_BLOCK / 64];
+    if (f.use_bvh) stage_bvh(sc, s_nodes, s_leaves);
+
+    const int count = PRIMARY ? f.pix_count : w.ctr[RT_C_RAY_COUNT + level];
+    const int link_in = PRIMARY ? 0 : w.ctr[RT_C_LINK_START + level];
+    const int link_out = w.ctr[RT_C_LINK_START + level + 1];
+    const float4* __restrict__ qa_in = w.q_a[level & 1];
+    const float4* __restrict__ qb_in = w.q_b[level & 1];
+    float4* __restrict__ qa_out = w.q_a[(level + 1) & 1];
+    float4* __restrict__ qb_out = w.q_b[(level + 1) & 1];
+    const int stride = gridDim.x * blockDim.x;
+    const int rounds = (count + stride - 1) / stride;
+    const bool spawn = level < f.max_depth;
+    unsigned n_primary = 0, n_refl = 0, n_refr = 0, n_refl_ref = 0;
+
+    for (int it = 0; it < rounds; ++it) {
+        const int i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool active = i < count;
+        Ray r; uint32_t path = 0; int slot = 0;
+        r.o = mk(0, 0, 0); r.d = mk(0, 0, 1); r.time = 0.0f;
+        if (active) {
+            if (PRIMARY) active = generate_primary(f, i, r, path, slot);
+            else {
+                float4 a = qa_in[i], b = qb_in[i];
+                r.o = mk(a.x, a.y, a.z); r.d = mk(a.w, b.x, b.y); r.time = 0.0f;   // secondary rays carry time 0 (ray.h:13)
+                path = (uint32_t)f2i(b.z);
+            }
+        }
+        if (PRIMARY && active) ++n_primary;
+        Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
+        bool hit = active && trace<false>(sc, f, s_nodes, s_leaves, r, !PRIMARY && f.fallback_full, best);
+
+        // one node per hit
+        unsigned long long hm = __ballot(hit);
+        int node = -1;
+        {
+            int total = __popcll(hm);
+            int base = 0;
+            if (__lane_id() == 0 && total) base = atomicAdd(&w.ctr[RT_C_NODE], total);
+            base = __shfl(base, 0, 64);
+            if (hit) node = base + __popcll(hm & ((1ull << __lane_id()) - 1ull));
+        }
+        if (hit && (unsigned)node >= w.cap_nodes) { w.ctr[RT_C_ERR] = 1; hit = false; node = -1; }
+        if (!PRIMARY && active) w.link[link_in + i] = node;
+
+        int n_children = 0, n_reflect = 0; bool refract = false;
+        HitOut h; V3 N = mk(0, 0, 1), rd = mk(0, 0, 1), fd = mk(0, 0, 1); float weight = 0.0f, gloss_angle = 0.0f; bool glossy = false;
+        if (hit) {
+            full_hit(sc, f, r, best, h);
+            w.n_a[node] = make_float4(h.p.x, h.p.y, h.p.z, r.time);
+            w.n_b[node] = make_float4(h.n.x, h.n.y, h.n.z, i2f(h.gid));
+            if (f.textures) w.n_uv[node] = make_float2(h.u, h.v);
+            if (PRIMARY) w.n_pix[node] = slot;
+            if (spawn) {
+                float4 m0 = sc.mats[3 * h.gid], m1 = sc.mats[3 * h.gid + 1], m2 = sc.mats[3 * h.gid + 2];
+                float reflectivity = m2.z;                               // raytracer.cpp:374-375, evaluated on the host
+                float ior = m2.x > 0.0f ? m2.x : 1.0f;
+                float transparency = m1.w;
+                V3 cam = mk(f.cam_loc[0], f.cam_loc[1], f.cam_loc[2]);
+                V3 V = normalise(cam - h.p);                             // raytracer.cpp:381-382: always from the camera
+                N = h.n;
+                if (dot(r.d, N) > 0.0f) N = mk(-N.x, -N.y, -N.z);        // raytracer.cpp:386-390
+                if (reflectivity > 0) {                                  // raytracer.cpp:395-413
+                    float incoming = dot(r.d, N);
+                    rd = normalise(mk(r.d.x - 2.0f * incoming * N.x, r.d.y - 2.0f * incoming * N.y, r.d.z - 2.0f * incoming * N.z));
+                    glossy = f.glossy && m0.w > 0.0f;
+                    if (glossy) gloss_angle = (float)((double)smax(0.01f, (1.0f - smin(1.0f, m0.w / 128.0f))) * (M_PI / 6.0));
+                    // without glossy perturbation all gr_samples rays are identical: trace one, replay the sum at resolve
+                    n_reflect = glossy ? f.gr_samples : 1;
+                }
+                if (transparency > 0) {                                  // raytracer.cpp:444-497
+                    float n1 = 1.0f, n2 = ior;
+                    float cos_i = dot(r.d, N);
+                    if (cos_i > 0) { float tt = n1; n1 = n2; n2 = tt; }
+                    float eta = n1 / n2;
+                    cos_i = -smax(-1.0f, smin(1.0f, cos_i));
+                    float k = 1.0f - eta * eta * (1.0f - cos_i * cos_i);
+                    if (!(k < 0.0f)) {
+                        float sq = sqrtf(k);
+                        fd = normalise(mk((r.d.x * eta) + (N.x * (eta * cos_i - sq)), (r.d.y * eta) + (N.y * (eta * cos_i - sq)),
+                                          (r.d.z * eta) + (N.z * (eta * cos_i - sq))));
+                        refract = true;
+                        float cosTheta = fabsf(dot(V, N));
+                        float q = (n1 - n2) / (n1 + n2);
+                        float r0 = (float)((double)q * (double)q);
+                        float fresnel = (float)((double)r0 + (double)(1.0f - r0) * pow((double)(1.0f - cosTheta), 5.0));
+                        weight = transparency * (1.0f - fresnel);
+                    }
+                }
+                n_children = n_reflect + (refract ? 1 : 0);
+            }
+        }
+        int first_link = wave_alloc(&w.ctr[RT_C_LINK], n_children);
+        if (hit) {
+            int qslot = first_link - link_out;
+            if (n_children > 0 && ((unsigned)(qslot + n_children) > w.cap_rays || (unsigned)(first_link + n_children) > w.cap_links)) {
+                w.ctr[RT_C_ERR] = 1; n_children = 0; n_reflect = 0; refract = false;
+            }
+            w.n_c[node] = make_float4(i2f(n_children ? first_link : -1), weight, i2f((int)path),
+                                      i2f(n_reflect | (refract ? (1 << 30) : 0)));
+            const float EPS = 1e-4f;
+            for (int j = 0; j < n_reflect; ++j) {                        // raytracer.cpp:415-421
+                V3 dir = rd;
+                uint32_t cpath = mix32(path * 0x9E3779B1u + (uint32_t)j + 1u);
+                if (glossy) {
+                    uint4 q = philox(path, (uint32_t)j, (uint32_t)level, STREAM_GLOSSY, f.seed, 0x52541u);
+                    dir = cone_direction(rd, gloss_angle, q.x, q.y);
+                }
+                V3 org = h.p + N * EPS;
+                qa_out[qslot + j] = make_float4(org.x, org.y, org.z, dir.x);
+                qb_out[qslot + j] = make_float4(dir.y, dir.z, i2f((int)cpath), 0.0f);
+            }
+            if (refract) {                                               // raytracer.cpp:474-479
+                V3 org = h.p + fd * EPS;
+                uint32_t cpath = mix32(path * 0x9E3779B1u + 0x7FFFFFFFu);
+                qa_out[qslot + n_reflect] = make_float4(org.x, org.y, org.z, fd.x);
+                qb_out[qslot + n_reflect] = make_float4(fd.y, fd.z, i2f((int)cpath), 0.0f);
+                ++n_refr;
+            }
+            n_refl += (unsigned)n_reflect;
+            if (n_reflect) n_refl_ref += (unsigned)f.gr_samples;
+        }
+    }
+    if (PRIMARY) block_stat_add(&w.stats[RT_S_PRIMARY], n_primary, s_tmp);
+    if (spawn) {
+        block_stat_add(&w.stats[RT_S_REFLECT], n_refl, s_tmp);
+        block_stat_add(&w.stats[RT_S_REFRACT], n_refr, s_tmp);
+        block_stat_add(&w.stats[RT_S_REFLECT_REF], n_refl_ref, s_tmp);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// shadow: one lane per (hit, light, sample).  Hard shadows (raytracer.cpp:509-530): any hit at any distance
+// blocks.  Soft shadows (raytracer.cpp:534-571): ss_samples rays to points in a ball around the light, blocked
+// when the reported hit is nearer than the sampled point.  Output = number of unblocked samples per (hit, light).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, DevFrame f, DevWork w) {
+    extern __shared__ float4 s_mem[];
+    float4* s_nodes = s_mem;
+    int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
+    __shared__ unsigned s_tmp[RT_BLOCK / 64];
+    if (f.use_bvh) stage_bvh(sc, s_nodes, s_leaves);
+
+    const int n_nodes = min(w.ctr[RT_C_NODE], (int)w.cap_nodes);
+    const int L = sc.n_lights;
+    const int SS = f.soft_shadows ? f.ss_samples : 1;
+    const int per = L * SS;
+    const long long count = (long long)n_nodes * per;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long rounds = (count + stride - 1) / stride;
+    const bool grouped = (SS <= 64) && ((SS & (SS - 1)) == 0);           // a (hit, light) group sits inside one wavefront
+    int* __restrict__ out = (int*)w.shadow;
+    unsigned n_rays = 0;
+
+    for (long long it = 0; it < rounds; ++it) {
+        const long long i = it * stride + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool active = i < count;
+        bool unblocked = false;
+        int node = 0, l = 0, j = 0;
+        if (active) {
+            node = (int)(i / per); int rem = (int)(i % per); l = rem / SS; j = rem % SS;
+            float4 a = w.n_a[node], b = w.n_b[node];
+            float4 lt = sc.lights[l];
+            V3 p = mk(a.x, a.y, a.z);
+            Ray sr; sr.time = a.w;
+            Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
+            ++n_rays;
+            if (!f.soft_shadows) {
+                V3 nrm = mk(b.x, b.y, b.z);
+                sr.d = normalise(mk(lt.x - p.x, lt.y - p.y, lt.z - p.z));
+                sr.o = p + nrm * 1e-2f;                                  // raytracer.cpp:515: unflipped geometric normal
+                unblocked = !trace<true>(sc, f, s_nodes, s_leaves, sr, false, best);
+            } else {
+                uint32_t path = (uint32_t)f2i(w.n_c[node].z);
+                uint4 q = philox(path, (uint32_t)l, (uint32_t)j, STREAM_SHADOW, f.seed, 0x52541u);
+                V3 jit = unit_sphere(u01(q.x), u01(q.y), u01(q.z)) * f.light_radius;
+                V3 lp = mk(lt.x + jit.x, lt.y + jit.y, lt.z + jit.z);
+                V3 h2l = lp - p;
+                V3 ld = normalise(h2l);
+                sr.o = p + ld * 0.001f;                                  // raytracer.cpp:549
+                sr.d = ld;
+                float lightDist = len_ref(h2l);                          // raytracer.cpp:553
+                bool hit = trace<false>(sc, f, s_nodes, s_leaves, sr, false, best);
+                unblocked = !(hit && best.t < lightDist);                // raytracer.cpp:564
+            }
+        }
+        if (grouped) {
+            unsigned long long m = __ballot(active && unblocked);
+            if (active && j == 0) {
+                int lane0 = __lane_id();
+                unsigned long long g = (SS == 64) ? m : ((m >> lane0) & ((1ull << SS) - 1ull));
+                out[node * L + l] = __popcll(g);
+            }
+        } else if (active && unblocked) {
+            atomicAdd(&out[node * L + l], 1);                            // buffer zeroed by the host for this layout
+        }
+    }
+    block_stat_add(&w.stats[RT_S_SHADOW], n_rays, s_tmp);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// shade + resolve for one recursion level, deepest level first: Blinn-Phong at the hit (raytracer.cpp:262-347),
+// then the parent's combination of its children's colours with both clamps (raytracer.cpp:436-503).  Level 0
+// adds the result to the pixel's running sum (raytracer.cpp:154).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, DevWork w, int level) {
+    __shared__ unsigned s_tmp[RT_BLOCK / 64];
+    const int begin = w.ctr[RT_C_NODE_START + level];
+    const int end = min(w.ctr[RT_C_NODE_START + level + 1], (int)w.cap_nodes);
+    const int count = end - begin;
+    const int stride = gridDim.x * blockDim.x;
+    const int L = sc.n_lights;
+    const int* __restrict__ sh = (const int*)w.shadow;
+    const V3 cam = mk(f.cam_loc[0], f.cam_loc[1], f.cam_loc[2]);
+    unsigned n_shaded = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+        const int node = begin + k;
+        ++n_shaded;
+        float4 a = w.n_a[node], b = w.n_b[node], c = w.n_c[node];
+        const int gid = f2i(b.w);
+        float4 m0 = sc.mats[3 * gid], m1 = sc.mats[3 * gid + 1], m2 = sc.mats[3 * gid + 2];
+        V3 p = mk(a.x, a.y, a.z), N = mk(b.x, b.y, b.z);
+        const float ka = 0.25f, shiny = m0.w;
+        V3 mat = mk(m0.x, m0.y, m0.z);
+        const int tex = f2i(m2.y);
+        if (f.textures && tex >= 0) {                                    // raytracer.cpp:271-297
+            float2 uv = w.n_uv[node];
+            int4 td = sc.tex_desc[tex];
+            float u = fmodf(uv.x, 1.0f); if (uv.x < 0) u += 1.0f;
+            float v = fmodf(uv.y, 1.0f); if (uv.y < 0) v += 1.0f;
+            int xi = (int)(u * (float)(td.x - 1)); if (td.x - 1 < xi) xi = td.x - 1;
+            int yi = (int)((1.0f - v) * (float)(td.y - 1)); if (td.y - 1 < yi) yi = td.y - 1;
+            if (xi < 0) xi = 0;                                          // the reference reads out of bounds here
+            if (yi < 0) yi = 0;
+            float4 tx = sc.texels[td.z + yi * td.x + xi];
+            mat = mk(tx.x, tx.y, tx.z);
+        }
+        V3 V = normalise(cam - p);
+        V3 col = mk(ka * mat.x, ka * mat.y, ka * mat.z);
+        for (int l = 0; l < L; ++l) {
+            float4 lt = sc.lights[l];
+            V3 Lv = mk(lt.x - p.x, lt.y - p.y, lt.z - p.z);
+            float L_len = len_ref(Lv);
+            Lv = normalise(Lv);
+            float irr = (float)((double)lt.w / ((double)1.0f + (double)L_len * (double)L_len));   // raytracer.cpp:320
+            V3 H = normalise(Lv + V);
+            float N_L = smax(0.0f, dot(N, Lv));
+            float N_H = smax(0.0f, dot(N, H));
+            int cnt = sh[node * L + l];
+            float shadow = f.soft_shadows ? (float)cnt / (float)f.ss_samples : (cnt ? 1.0f : 0.0f);
+            float pw = powf_ref(N_H, shiny);
+            col.x += shadow * mat.x * N_L * irr + 0.5f * m1.x * pw * irr;
+            col.y += shadow * mat.y * N_L * irr + 0.5f * m1.y * pw * irr;
+            col.z += shadow * mat.z * N_L * irr + 0.5f * m1.z * pw * irr;
+        }
+        col.x = smin(1.0f, smax(col.x, 0.0f));                           // raytracer.cpp:342-344
+        col.y = smin(1.0f, smax(col.y, 0.0f));
+        col.z = smin(1.0f, smax(col.z, 0.0f));
+
+        if (level < f.max_depth) {                                       // raytracer.cpp:369-503
+            const int first = f2i(c.x), packed = f2i(c.w);
+            const int n_reflect = packed & 0x3fffffff;
+            const bool refract = (packed >> 30) & 1;
+            const float reflectivity = m2.z;
+            V3 rc = mk(0.0f, 0.0f, 0.0f);
+            if (n_reflect == 1) {
+                int ch = w.link[first];
+                V3 cc = mk(0.0f, 0.0f, 0.0f);
+                if (ch >= 0) { float4 q = w.n_col[ch]; cc = mk(q.x, q.y, q.z); }
+                for (int s = 0; s < f.gr_samples; ++s) rc = rc + cc;     // the gr_samples identical rays of raytracer.cpp:400-432
+            } else {
+                for (int s = 0; s < n_reflect; ++s) {
+                    int ch = w.link[first + s];
+                    if (ch >= 0) { float4 q = w.n_col[ch]; rc = rc + mk(q.x, q.y, q.z); }
+                    else rc = rc + mk(0.0f, 0.0f, 0.0f);
+                }
+            }
+            const float inv = 1.0f / (float)f.gr_samples;                // raytracer.cpp:436-439
+            rc = rc * inv;
+            rc = rc * reflectivity;
+            col = col + rc;
+            if (refract) {                                               // raytracer.cpp:494-497
+                int ch = w.link[first + n_reflect];
+                V3 fc = mk(0.0f, 0.0f, 0.0f);
+                if (ch >= 0) { float4 q = w.n_col[ch]; fc = mk(q.x, q.y, q.z); }
+                col = col + fc * c.y;
+            }
+            col.x = smin(1.0f, smax(0.0f, col.x));                       // raytracer.cpp:501-503
+            col.y = smin(1.0f, smax(0.0f, col.y));
+            col.z = smin(1.0f, smax(0.0f, col.z));
+        }
+        w.n_col[node] = make_float4(col.x, col.y, col.z, 0.0f);
+        if (level == 0) {
+            const int slot = w.n_pix[node];
+            float4 acc = w.accum[slot];
+            w.accum[slot] = make_float4(acc.x + col.x, acc.y + col.y, acc.z + col.z, 0.0f);
+        }
+    }
+    block_stat_add(&w.stats[RT_S_NODES], n_shaded, s_tmp);
+}
+
+// raytracer.cpp:171-178: average over the samples and truncate to 0..255.
+__global__ void k_finalize(DevFrame f, DevWork w, unsigned char* __restrict__ out, int tile_major, int n_slots, int samples) {
+    const float inv = 1.0f / (float)samples;
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_slots; slot += gridDim.x * blockDim.x) {
+        float4 acc = w.accum[slot];
+        int r = (int)(255.0f * (acc.x * inv)), g = (int)(255.0f * (acc.y * inv)), b = (int)(255.0f * (acc.z * inv));
+        if (tile_major) {
+            out[3 * slot] = (unsigned char)r; out[3 * slot + 1] = (unsigned char)g; out[3 * slot + 2] = (unsigned char)b;
+        } else {
+            int tile_local = slot / RT_TILE_PIX, in = slot % RT_TILE_PIX;
+            int gt = f.local_tiles[tile_local];
+            int x = (gt % f.tiles_x) * RT_TILE + (in % RT_TILE), y = (gt / f.tiles_x) * RT_TILE + (in / RT_TILE);
+            if (x < f.width && y < f.height) {
+                size_t o = ((size_t)y * f.width + x) * 3;
+                out[o] = (unsigned char)r; out[o + 1] = (unsigned char)g; out[o + 2] = (unsigned char)b;
+            }
+        }
+    }
+}
+
+// Gathered per-rank tile blocks -> row-major image.  Tile (tx,ty) belongs to rank (tx+ty) % world and is that
+// rank's k-th tile in ascending global tile order.
+__global__ void k_assemble(const unsigned char* __restrict__ tiles, int world, int max_tiles, int tiles_x, int tiles_y,
+                           int width, int height, unsigned char* __restrict__ out) {
+    const int n = width * height;
+    for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < n; pix += gridDim.x * blockDim.x) {
+        int x = pix % width, y = pix / width;
+        int tx = x / RT_TILE, ty = y / RT_TILE;
+        int owner = (tx + ty) % world;
+        // tiles of `owner` before (tx,ty): full rows above plus this row's tiles left of tx
+        int k = 0;
+        for (int row = 0; row < ty; ++row) {
+            int first = ((owner - row) % world + world) % world;         // smallest tx in that row owned by `owner`
+            if (first < tiles_x) k += (tiles_x - 1 - first) / world + 1;
+        }
+        {
+            int first = ((owner - ty) % world + world) % world;
+            if (tx > first) k += (tx - 1 - first) / world + 1;
+        }
+        size_t src = (((size_t)owner * max_tiles + k) * RT_TILE_PIX + (size_t)(y % RT_TILE) * RT_TILE + (x % RT_TILE)) * 3;
+        size_t dst = (size_t)pix * 3;
+        out[dst] = tiles[src]; out[dst + 1] = tiles[src + 1]; out[dst + 2] = tiles[src + 2];
+    }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+static size_t bvh_lds_bytes(const DevScene& sc, const DevFrame& f) {
+    return f.use_bvh ? (size_t)(2 * sc.n_nodes + 2 * sc.n_leaves) * 16 : 16;
+}
+
+void rt_launch_level_begin(hipStream_t s, const DevWork& w, int level) {
+    hipLaunchKernelGGL(k_level_begin, dim3(1), dim3(1), 0, s, w, level);
+}
+
+void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {
+    size_t lds = bvh_lds_bytes(sc, f);
+    if (level == 0) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+}
+
+void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid) {
+    hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w);
+}
+
+void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, s, sc, f, w, level);
+}
+
+void rt_launch_finalize(hipStream_t s, const DevFrame& f, const DevWork& w, unsigned char* out, int tile_major, int n_slots, int samples) {
+    int grid = (n_slots + RT_BLOCK - 1) / RT_BLOCK; if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(RT_BLOCK), 0, s, f, w, out, tile_major, n_slots, samples);
+}
+
+void rt_launch_assemble(hipStream_t s, const unsigned char* tiles, int world, int max_tiles, int tiles_x, int tiles_y,
+                        int width, int height, unsigned char* out) {
+    int n = width * height;
+    int grid = (n + RT_BLOCK - 1) / RT_BLOCK; if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(RT_BLOCK), 0, s, tiles, world, max_tiles, tiles_x, tiles_y, width, height, out);
+}

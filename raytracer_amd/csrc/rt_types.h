@@ -1,0 +1,115 @@
+// Device-side layouts shared by the kernels (rt_kernels.hip) and the context (rt_context.hip).
+// Everything lives in HBM as arrays of 16-byte words so that a lane's record is one or a few dwordx4 loads.
+#ifndef RT_TYPES_H
+#define RT_TYPES_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_TILE        32            // image tiles are RT_TILE x RT_TILE pixels; a wavefront covers two tile rows
+#define RT_TILE_PIX    (RT_TILE * RT_TILE)
+#define RT_BLOCK       256           // threads per workgroup = 4 wavefronts
+#define RT_MAX_LEVELS  34            // recursion levels 0..32 plus one end marker
+#define RT_MAX_LDS_NODES   1024      // BVH nodes staged in LDS (32 B each)
+#define RT_MAX_LDS_LEAVES  512       // leaf records staged in LDS (32 B each)
+
+// ---- primitives ---------------------------------------------------------------------------------------
+// A primitive set is one ordering of the scene's primitives: leaf order (BVH traversal) or file order
+// (brute force, which must visit planes, cubes, spheres in the order of the scene file).
+//   plane  : 3 words  w0 = (n.x, n.y, n.z, bits first_vert)
+//                     w1 = (v0.x, v0.y, v0.z, bits n_verts | drop_axis << 16)   v0 = vertex the plane offset uses
+//                     w2 = (bits gid, 0, 0, 0)
+//   vertex : 1 word   (x, y, z, 0)  winding-sorted polygon vertices
+//   cube   : 6 words  w0 = (start.xyz, scale)  w1 = (end.xyz, 1/scale)
+//                     w2 = (cos rx, sin rx, cos ry, sin ry)  w3 = (cos rz, sin rz, bits gid, 0)
+//                     w4 = (cos -rz, sin -rz, cos -ry, sin -ry)  w5 = (cos -rx, sin -rx, 0, 0)
+//   sphere : 2 words  w0 = (start.xyz, radius)  w1 = (end.xyz, bits gid)
+// gid = index in scene-file order over planes, then cubes, then spheres; materials are indexed by it.
+struct DevPrimSet {
+    const float4* planes;
+    const float4* verts;
+    const float4* cubes;
+    const float4* spheres;
+    int n_planes, n_cubes, n_spheres;
+};
+
+// material: 3 words  m0 = (diffuse.rgb, shininess)  m1 = (specular.rgb, transparency)
+//                    m2 = (ior, bits tex_id, reflectivity, 0)
+// plane uv : 3 words per plane gid  (uAxis.xyz, uLen) (vAxis.xyz, vLen) (sorted v0.xyz, 0)
+// texture  : descriptor (width, height, first texel, 0); texels are (r/255, g/255, b/255, 0)
+// light    : (x, y, z, radiant intensity)
+// BVH node : 2 words (min.xyz, bits skip) (max.xyz, bits leaf | -1), laid out in the order a traversal that
+//            visits the right child first meets them; skip = index of the next node once this subtree is done.
+// leaf     : 2 words of ints (plane_first, plane_count, cube_first, cube_count) (sphere_first, sphere_count, 0, 0)
+struct DevScene {
+    const float4* nodes;  int n_nodes;
+    const int4* leaves;   int n_leaves;
+    DevPrimSet leafset;
+    DevPrimSet fileset;
+    const float4* mats;
+    const float4* plane_uv;
+    const int4* tex_desc;
+    const float4* texels;
+    const float4* lights; int n_lights;
+};
+
+struct DevFrame {
+    // camera (per-frame constants of Camera::convertPixelToRay)
+    float cam_loc[3], fwd[3], right[3], up[3];
+    float sw_over_fl, sh_over_fl, res_x, res_y, lens_radius, focal_distance;
+    int width, height;
+    // config
+    int soft_shadows, ss_samples, glossy, gr_samples, anti_aliasing, aa_n, dof_on, dof_n, mb_on, mb_n;
+    int textures, use_bvh, fallback_full, motion_blur, max_depth;
+    float light_radius;
+    uint32_t seed;
+    // sharding
+    int tiles_x, tiles_y, n_local_tiles;
+    const int* local_tiles;        // global tile ids rendered by this rank, ascending
+    // this batch
+    int pix_begin, pix_count;      // range of local pixel slots (tile-major) covered by the batch
+    int sample;                    // sample index s = (s_aa * dof_n + s_dof) * mb_n + s_mb
+};
+
+// ---- work buffers ---------------------------------------------------------------------------------------
+// Hit-tree node (one per shaded hit), structure of arrays:
+//   n_a = (hit point xyz, hit time)           n_b = (geometric normal xyz, bits gid)
+//   n_c = (bits first_link | -1, refraction weight, bits path id, bits n_reflection_children | has_refraction << 30)
+//   n_uv = (u, v) when texture mapping is on   n_col = resolved colour (r, g, b, 0)
+//   n_pix (level 0 only) = local pixel slot
+// Secondary-ray queue entry: q_a = (origin xyz, dir.x)  q_b = (dir.y, dir.z, bits path id, 0)
+// link[k] = node index hit by spawned ray k, or -1
+struct DevWork {
+    float4* q_a[2]; float4* q_b[2];
+    float4* n_a; float4* n_b; float4* n_c; float2* n_uv; float4* n_col; int* n_pix;
+    float* shadow;
+    int* link;
+    float4* accum;                 // per local pixel slot: running colour sum over samples
+    int* ctr;                      // counters, see below
+    unsigned long long* stats;     // ray counters, see below
+    unsigned cap_nodes, cap_rays, cap_links;
+};
+
+// ctr[] slots
+enum {
+    RT_C_NODE = 0,                 // nodes allocated in this batch
+    RT_C_LINK = 1,                 // links (= secondary rays) allocated in this batch
+    RT_C_ERR = 2,                  // set when a capacity was exceeded
+    RT_C_NODE_START = 8,           // [level] first node of the level; [max_depth+1] = end
+    RT_C_LINK_START = 8 + RT_MAX_LEVELS,      // [level] first link of the rays traced at `level`
+    RT_C_RAY_COUNT = 8 + 2 * RT_MAX_LEVELS,   // [level] secondary rays to trace at `level` (level >= 1)
+    RT_C_TOTAL = 8 + 3 * RT_MAX_LEVELS
+};
+// stats[] slots
+enum { RT_S_PRIMARY = 0, RT_S_SHADOW, RT_S_REFLECT, RT_S_REFRACT, RT_S_REFLECT_REF, RT_S_NODES, RT_S_TOTAL = 8 };
+
+// kernel launchers (rt_kernels.hip)
+void rt_launch_level_begin(hipStream_t s, const DevWork& w, int level);
+void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);
+void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid);
+void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);
+void rt_launch_finalize(hipStream_t s, const DevFrame& f, const DevWork& w, unsigned char* out, int tile_major, int n_slots, int samples);
+void rt_launch_assemble(hipStream_t s, const unsigned char* tiles, int world, int max_tiles, int tiles_x, int tiles_y,
+                        int width, int height, unsigned char* out);
+
+#endif

@@ -1,0 +1,76 @@
+"""Scene / flag-set catalogue shared by the golden generator (tests/golden/make_golden.py) and the tests."""
+from __future__ import annotations
+
+import re
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle"))
+
+from raytracer_amd import scenegen as sg  # noqa: E402
+
+GOLDEN = ROOT / "tests" / "golden"
+TEXTURES = GOLDEN / "textures"
+
+_RES_RE = re.compile(r'("film_resolution"\s*:\s*\{\s*"width"\s*:\s*)([0-9.]+)(\s*,\s*"height"\s*:\s*)([0-9.]+)')
+
+
+def with_resolution(text: str, w: int, h: int) -> str:
+    out, n = _RES_RE.subn(lambda m: f"{m.group(1)}{w}{m.group(3)}{h}", text, count=1)
+    assert n == 1
+    return out
+
+
+def reference_scene(w: int = 1920, h: int = 1080) -> str:
+    """The reference's own ASCII/scene.json (committed as a data fixture), optionally at another film size."""
+    return with_resolution((GOLDEN / "scene.json").read_text(), w, h)
+
+
+SCENES = {
+    "ref": lambda: reference_scene(240, 135),
+    "glass": lambda: sg.glass_scene((200, 112)),
+    "glass_tex": lambda: sg.glass_scene((200, 112), True),
+    "cluster16": lambda: sg.cluster_scene(16, 7, (200, 112)),
+    "rand200": lambda: sg.random_scene(200, 42, (160, 90), rmin=0.2, rmax=0.6, transparent_frac=0.2, moving=True),
+}
+
+# Deterministic flag sets: the image is a pure function of scene + flags; the bar is +-1 LSB per channel.
+DETERMINISTIC = [
+    ("ref", []),
+    ("ref", ["-u"]),
+    ("ref", ["-r"]),
+    ("ref", ["-rd", "4", "-grs", "1"]),
+    ("ref", ["-rd", "3", "-grs", "2"]),
+    ("glass", []),
+    ("glass", ["-u"]),
+    ("glass", ["-rd", "3", "-grs", "1"]),
+    ("glass", ["-u", "-rd", "3", "-grs", "1"]),
+    ("glass", ["-rd", "2"]),
+    ("glass_tex", ["-t"]),
+    ("glass_tex", ["-t", "-u"]),
+    ("glass_tex", ["-t", "-rd", "2", "-grs", "1"]),
+    ("cluster16", []),
+    ("cluster16", ["-u"]),
+    ("cluster16", ["-rd", "3", "-grs", "1"]),
+    ("cluster16", ["-u", "-rd", "3", "-grs", "1"]),
+    ("rand200", []),
+    ("rand200", ["-u"]),
+    ("rand200", ["-rd", "2", "-grs", "1"]),
+]
+
+# Stochastic flag sets: judged by PSNR >= 40 dB between two high-sample renders (the golden one is the reference's).
+STOCHASTIC = [
+    ("ref", ["-aa", "-aas", "256"]),
+    ("ref", ["-ss", "-sss", "256"]),
+    ("ref", ["-dof", "-dofs", "256"]),
+    ("ref", ["-m", "-mbs", "256"]),
+    ("ref", ["-r", "-gr", "-grs", "256"]),
+    ("glass_tex", ["-t", "-aa", "-aas", "16", "-ss", "-sss", "16", "-r", "-grs", "1"]),
+    ("ref", ["-aa", "-aas", "4", "-dof", "-dofs", "8", "-m", "-mbs", "8", "-ss", "-sss", "8"]),
+]
+
+
+def case_id(scene: str, flags: list[str]) -> str:
+    return scene + ("_" + "".join(f.replace("-", "") for f in flags) if flags else "_default")
