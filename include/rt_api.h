@@ -153,10 +153,18 @@ typedef struct rt_stats {
     uint64_t shadow_rays;
     uint64_t reflection_rays;     /* traced; identical copies the reference would re-trace are not counted here */
     uint64_t refraction_rays;
-    uint64_t reflection_rays_ref; /* what the reference would trace (x gr_samples when glossy is off) */
     uint64_t nodes_shaded;        /* hits that went through Blinn-Phong */
+    /* what the reference itself would trace for this frame: without -gr it re-traces gr_samples identical
+       reflection rays per hit together with everything below them (raytracer.cpp:400-432) */
+    uint64_t shadow_rays_ref;
+    uint64_t reflection_rays_ref;
+    uint64_t refraction_rays_ref;
     uint64_t batches;             /* pipeline passes (one per sample index per pixel chunk) */
+    uint64_t launches_extend, launches_shadow, launches_shade;
     double   ms_total;            /* rt_render*: enqueue -> results ready, host wall clock */
+    /* device time per stage, summed over the frame, from HIP events on the render stream; filled only when
+       the frame has at most 64 batches (0 otherwise) */
+    double   ms_extend, ms_shadow, ms_shade, ms_other;
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -108,6 +108,7 @@ struct rt_ctx {
     DevBuf<float> shadow;
     DevBuf<unsigned long long> stats;
     DevBuf<unsigned char> out_tmp;
+    unsigned long long last_batches = 0;
 
     int fail(int code, const char* fmt, ...) {
         char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -436,8 +437,36 @@ int rt_set_shard(rt_ctx* c, int32_t rank, int32_t world) {
 int32_t rt_local_tiles(const rt_ctx* c) { return c ? (int32_t)c->local_tiles.size() : 0; }
 int32_t rt_max_tiles_per_rank(const rt_ctx* c) { return c ? c->max_tiles : 0; }
 
+// Per-stage device timing of one frame: an event pair around every launch (only used when the caller asked for
+// statistics and the frame is short enough for that to be cheap).
+struct StageTimer {
+    struct Span { hipEvent_t a, b; int stage; };
+    std::vector<Span> spans;
+    hipStream_t s = nullptr;
+    bool on = false;
+    unsigned long long launches[4] = { 0, 0, 0, 0 };
+    void begin(int stage) {
+        launches[stage]++;
+        if (!on) return;
+        Span sp{}; sp.stage = stage;
+        if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(sp.a, s); spans.push_back(sp);
+    }
+    void end() { if (on && !spans.empty()) (void)hipEventRecord(spans.back().b, s); }
+    void collect(double ms[4]) {
+        for (int i = 0; i < 4; ++i) ms[i] = 0.0;
+        for (auto& sp : spans) {
+            float t = 0.0f;
+            if (on && hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) ms[sp.stage] += t;
+            (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);
+        }
+        spans.clear();
+    }
+};
+enum { ST_EXTEND = 0, ST_SHADOW = 1, ST_SHADE = 2, ST_OTHER = 3 };
+
 // Enqueue one frame.  out_dev: device buffer in the layout rt_render_device documents.
-static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev, bool want_stats_zero) {
+static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev, bool want_stats_zero, StageTimer* tm) {
     if (!c->have_scene) return c->fail(RT_ERR_STATE, "render before rt_upload_scene");
     if (cfg->bvh && !c->have_bvh) return c->fail(RT_ERR_STATE, "config asks for the BVH but none was uploaded");
     const int AA = cfg->anti_aliasing ? cfg->aa_samples : 1;
@@ -519,6 +548,10 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
 
     const int max_grid = 2048;       // 256 CUs x 8 workgroups: enough to fill the chip, grid-stride beyond that
     unsigned long long batches = 0;
+    StageTimer local_tm; if (!tm) tm = &local_tm;
+    tm->s = s;
+    const unsigned long long n_batches = (unsigned long long)((n_slots + B - 1) / B) * (unsigned long long)S;
+    if (n_batches > 64) tm->on = false;
     for (long long begin = 0; begin < n_slots; begin += B) {
         const int count = (int)std::min<long long>(B, n_slots - begin);
         f.pix_begin = (int)begin; f.pix_count = count;
@@ -528,12 +561,18 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
             RT_HIP(c, hipMemsetAsync(c->ctr.p, 0, 2 * sizeof(int), s));     // RT_C_NODE, RT_C_LINK
             for (int level = 0; level <= D; ++level) {
                 rt_launch_level_begin(s, w, level);
+                tm->begin(ST_EXTEND);
                 rt_launch_extend(s, c->scene, f, w, level, level == 0 ? grid0 : max_grid);
+                tm->end();
             }
             rt_launch_level_begin(s, w, D + 1);
             if (!grouped) RT_HIP(c, hipMemsetAsync(c->shadow.p, 0, cap_nodes * (size_t)std::max(L, 1) * sizeof(float), s));
-            if (L > 0) rt_launch_shadow(s, c->scene, f, w, max_grid);
-            for (int level = D; level >= 0; --level) rt_launch_shade(s, c->scene, f, w, level, level == 0 ? grid0 : max_grid);
+            if (L > 0) { tm->begin(ST_SHADOW); rt_launch_shadow(s, c->scene, f, w, max_grid); tm->end(); }
+            for (int level = D; level >= 0; --level) {
+                tm->begin(ST_SHADE);
+                rt_launch_shade(s, c->scene, f, w, level, level == 0 ? grid0 : max_grid);
+                tm->end();
+            }
             ++batches;
         }
     }
@@ -542,24 +581,31 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         size_t total = (size_t)c->max_tiles * RT_TILE_PIX * 3, used = (size_t)n_slots * 3;
         if (total > used) RT_HIP(c, hipMemsetAsync(out_dev + used, 0, total - used, s));
     }
+    tm->begin(ST_OTHER);
     rt_launch_finalize(s, f, w, out_dev, tile_major, (int)n_slots, S);
+    tm->end();
     RT_HIP(c, hipGetLastError());
     c->err.clear();
-    (void)batches;
+    c->last_batches = batches;
     return RT_OK;
 }
 
-static int finish_stats(rt_ctx* c, rt_stats* st, double ms, unsigned long long batches_hint) {
+static int finish_stats(rt_ctx* c, rt_stats* st, double ms, StageTimer* tm) {
     int ctr[4] = { 0, 0, 0, 0 };
     unsigned long long hs[RT_S_TOTAL];
     RT_HIP(c, hipMemcpyAsync(ctr, c->ctr.p, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipMemcpyAsync(hs, c->stats.p, sizeof hs, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     if (st) {
+        std::memset(st, 0, sizeof *st);
         st->primary_rays = hs[RT_S_PRIMARY]; st->shadow_rays = hs[RT_S_SHADOW]; st->reflection_rays = hs[RT_S_REFLECT];
-        st->refraction_rays = hs[RT_S_REFRACT]; st->reflection_rays_ref = hs[RT_S_REFLECT_REF]; st->nodes_shaded = hs[RT_S_NODES];
-        st->batches = batches_hint; st->ms_total = ms;
-    }
+        st->refraction_rays = hs[RT_S_REFRACT]; st->nodes_shaded = hs[RT_S_NODES];
+        st->shadow_rays_ref = hs[RT_S_SHADOW_REF]; st->reflection_rays_ref = hs[RT_S_REFLECT_REF]; st->refraction_rays_ref = hs[RT_S_REFRACT_REF];
+        st->batches = c->last_batches; st->ms_total = ms;
+        double sm[4]; tm->collect(sm);
+        st->ms_extend = sm[ST_EXTEND]; st->ms_shadow = sm[ST_SHADOW]; st->ms_shade = sm[ST_SHADE]; st->ms_other = sm[ST_OTHER];
+        st->launches_extend = tm->launches[ST_EXTEND]; st->launches_shadow = tm->launches[ST_SHADOW]; st->launches_shade = tm->launches[ST_SHADE];
+    } else { double sm[4]; tm->collect(sm); }
     if (ctr[RT_C_ERR]) return c->fail(RT_ERR_CAPACITY, "a work buffer overflowed during the frame; the image is incomplete");
     return RT_OK;
 }
@@ -567,11 +613,13 @@ static int finish_stats(rt_ctx* c, rt_stats* st, double ms, unsigned long long b
 int rt_render_device(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev, rt_stats* stats) {
     if (!c || !cfg || !rgb_out_dev) return RT_ERR_ARG;
     auto t0 = std::chrono::steady_clock::now();
-    RT_TRY(enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true));
+    StageTimer tm; tm.on = stats != nullptr;
+    int rc = enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true, &tm);
+    if (rc != RT_OK) { double sm[4]; (void)hipStreamSynchronize(c->stream); tm.collect(sm); return rc; }
     if (!stats) return RT_OK;
     RT_HIP(c, hipStreamSynchronize(c->stream));
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return finish_stats(c, stats, ms, 0);
+    return finish_stats(c, stats, ms, &tm);
 }
 
 int rt_render(rt_ctx* c, const rt_config* cfg, uint8_t* rgb_out, rt_stats* stats) {
@@ -582,11 +630,13 @@ int rt_render(rt_ctx* c, const rt_config* cfg, uint8_t* rgb_out, rt_stats* stats
                                       : (size_t)((int)c->camera.res_x) * (size_t)((int)c->camera.res_y) * 3;
     if (bytes > c->out_tmp.n) { RT_HIP(c, hipStreamSynchronize(c->stream)); RT_HIP(c, c->out_tmp.resize(bytes)); }
     auto t0 = std::chrono::steady_clock::now();
-    RT_TRY(enqueue_frame(c, cfg, c->out_tmp.p, true));
+    StageTimer tm; tm.on = stats != nullptr;
+    int rc = enqueue_frame(c, cfg, c->out_tmp.p, true, &tm);
+    if (rc != RT_OK) { double sm[4]; (void)hipStreamSynchronize(c->stream); tm.collect(sm); return rc; }
     RT_HIP(c, hipStreamSynchronize(c->stream));
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     RT_HIP(c, hipMemcpy(rgb_out, c->out_tmp.p, bytes, hipMemcpyDeviceToHost));
-    return finish_stats(c, stats, ms, 0);
+    return finish_stats(c, stats, ms, &tm);
 }
 
 int rt_assemble_tiles(rt_ctx* c, const void* tiles_dev, int32_t world, void* rgb_out_dev) {

@@ -374,7 +374,7 @@ DEVI int wave_alloc(int* counter, int n) {
 }
 
 // Sum a per-thread count over the workgroup and add it to a 64-bit statistic with one atomic.
-DEVI void block_stat_add(unsigned long long* stat, unsigned v, unsigned* s_tmp) {
+DEVI void block_stat_add(unsigned long long* stat, unsigned long long v, unsigned long long* s_tmp) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, DevFrame f, De
     extern __shared__ float4 s_mem[];
     float4* s_nodes = s_mem;
     int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
-    __shared__ unsigned s_tmp[RT_BLOCK / 64];
+    __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
     if (f.use_bvh) stage_bvh(sc, s_nodes, s_leaves);
 
     const int count = PRIMARY ? f.pix_count : w.ctr[RT_C_RAY_COUNT + level];
@@ -477,19 +477,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, DevFrame f, De
     const int stride = gridDim.x * blockDim.x;
     const int rounds = (count + stride - 1) / stride;
     const bool spawn = level < f.max_depth;
-    unsigned n_primary = 0, n_refl = 0, n_refr = 0, n_refl_ref = 0;
+    unsigned long long n_primary = 0, n_refl = 0, n_refr = 0, n_shadow_ref = 0, n_refl_ref = 0, n_refr_ref = 0;
+    const unsigned long long shadow_per_hit = (unsigned long long)sc.n_lights * (f.soft_shadows ? f.ss_samples : 1);
 
     for (int it = 0; it < rounds; ++it) {
         const int i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         bool active = i < count;
-        Ray r; uint32_t path = 0; int slot = 0;
+        Ray r; uint32_t path = 0, mult = 1; int slot = 0;
         r.o = mk(0, 0, 0); r.d = mk(0, 0, 1); r.time = 0.0f;
         if (active) {
             if (PRIMARY) active = generate_primary(f, i, r, path, slot);
             else {
                 float4 a = qa_in[i], b = qb_in[i];
                 r.o = mk(a.x, a.y, a.z); r.d = mk(a.w, b.x, b.y); r.time = 0.0f;   // secondary rays carry time 0 (ray.h:13)
-                path = (uint32_t)f2i(b.z);
+                path = (uint32_t)f2i(b.z); mult = (uint32_t)f2i(b.w);
             }
         }
         if (PRIMARY && active) ++n_primary;
@@ -512,6 +513,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, DevFrame f, De
         int n_children = 0, n_reflect = 0; bool refract = false;
         HitOut h; V3 N = mk(0, 0, 1), rd = mk(0, 0, 1), fd = mk(0, 0, 1); float weight = 0.0f, gloss_angle = 0.0f; bool glossy = false;
         if (hit) {
+            n_shadow_ref += shadow_per_hit * mult;
             full_hit(sc, f, r, best, h);
             w.n_a[node] = make_float4(h.p.x, h.p.y, h.p.z, r.time);
             w.n_b[node] = make_float4(h.n.x, h.n.y, h.n.z, i2f(h.gid));
@@ -565,6 +567,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, DevFrame f, De
             w.n_c[node] = make_float4(i2f(n_children ? first_link : -1), weight, i2f((int)path),
                                       i2f(n_reflect | (refract ? (1 << 30) : 0)));
             const float EPS = 1e-4f;
+            // multiplicity of the children: each of the reference's gr_samples copies of a deduplicated ray
+            unsigned long long cm = (unsigned long long)mult * (unsigned)(n_reflect == 1 ? f.gr_samples : 1);
+            const uint32_t child_mult = cm > 0xffffffffull ? 0xffffffffu : (uint32_t)cm;
             for (int j = 0; j < n_reflect; ++j) {                        // raytracer.cpp:415-421
                 V3 dir = rd;
                 uint32_t cpath = mix32(path * 0x9E3779B1u + (uint32_t)j + 1u);
@@ -574,24 +579,26 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, DevFrame f, De
                 }
                 V3 org = h.p + N * EPS;
                 qa_out[qslot + j] = make_float4(org.x, org.y, org.z, dir.x);
-                qb_out[qslot + j] = make_float4(dir.y, dir.z, i2f((int)cpath), 0.0f);
+                qb_out[qslot + j] = make_float4(dir.y, dir.z, i2f((int)cpath), i2f((int)child_mult));
             }
             if (refract) {                                               // raytracer.cpp:474-479
                 V3 org = h.p + fd * EPS;
                 uint32_t cpath = mix32(path * 0x9E3779B1u + 0x7FFFFFFFu);
                 qa_out[qslot + n_reflect] = make_float4(org.x, org.y, org.z, fd.x);
-                qb_out[qslot + n_reflect] = make_float4(fd.y, fd.z, i2f((int)cpath), 0.0f);
-                ++n_refr;
+                qb_out[qslot + n_reflect] = make_float4(fd.y, fd.z, i2f((int)cpath), i2f((int)mult));
+                ++n_refr; n_refr_ref += mult;
             }
             n_refl += (unsigned)n_reflect;
-            if (n_reflect) n_refl_ref += (unsigned)f.gr_samples;
+            if (n_reflect) n_refl_ref += (unsigned long long)mult * (unsigned)f.gr_samples;
         }
     }
     if (PRIMARY) block_stat_add(&w.stats[RT_S_PRIMARY], n_primary, s_tmp);
+    block_stat_add(&w.stats[RT_S_SHADOW_REF], n_shadow_ref, s_tmp);
     if (spawn) {
         block_stat_add(&w.stats[RT_S_REFLECT], n_refl, s_tmp);
         block_stat_add(&w.stats[RT_S_REFRACT], n_refr, s_tmp);
         block_stat_add(&w.stats[RT_S_REFLECT_REF], n_refl_ref, s_tmp);
+        block_stat_add(&w.stats[RT_S_REFRACT_REF], n_refr_ref, s_tmp);
     }
 }
 
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, DevFrame f, De
     extern __shared__ float4 s_mem[];
     float4* s_nodes = s_mem;
     int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
-    __shared__ unsigned s_tmp[RT_BLOCK / 64];
+    __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
     if (f.use_bvh) stage_bvh(sc, s_nodes, s_leaves);
 
     const int n_nodes = min(w.ctr[RT_C_NODE], (int)w.cap_nodes);
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, DevFrame f, De
     const long long rounds = (count + stride - 1) / stride;
     const bool grouped = (SS <= 64) && ((SS & (SS - 1)) == 0);           // a (hit, light) group sits inside one wavefront
     int* __restrict__ out = (int*)w.shadow;
-    unsigned n_rays = 0;
+    unsigned long long n_rays = 0;
 
     for (long long it = 0; it < rounds; ++it) {
         const long long i = it * stride + (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -670,7 +677,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, DevFrame f, De
 // adds the result to the pixel's running sum (raytracer.cpp:154).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, DevWork w, int level) {
-    __shared__ unsigned s_tmp[RT_BLOCK / 64];
+    __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
     const int begin = w.ctr[RT_C_NODE_START + level];
     const int end = min(w.ctr[RT_C_NODE_START + level + 1], (int)w.cap_nodes);
     const int count = end - begin;
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, Dev
     const int L = sc.n_lights;
     const int* __restrict__ sh = (const int*)w.shadow;
     const V3 cam = mk(f.cam_loc[0], f.cam_loc[1], f.cam_loc[2]);
-    unsigned n_shaded = 0;
+    unsigned long long n_shaded = 0;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
         const int node = begin + k;
         ++n_shaded;

@@ -77,7 +77,7 @@ struct DevFrame {
 //   n_c = (bits first_link | -1, refraction weight, bits path id, bits n_reflection_children | has_refraction << 30)
 //   n_uv = (u, v) when texture mapping is on   n_col = resolved colour (r, g, b, 0)
 //   n_pix (level 0 only) = local pixel slot
-// Secondary-ray queue entry: q_a = (origin xyz, dir.x)  q_b = (dir.y, dir.z, bits path id, 0)
+// Secondary-ray queue entry: q_a = (origin xyz, dir.x)  q_b = (dir.y, dir.z, bits path id, bits multiplicity)
 // link[k] = node index hit by spawned ray k, or -1
 struct DevWork {
     float4* q_a[2]; float4* q_b[2];
@@ -101,7 +101,9 @@ enum {
     RT_C_TOTAL = 8 + 3 * RT_MAX_LEVELS
 };
 // stats[] slots
-enum { RT_S_PRIMARY = 0, RT_S_SHADOW, RT_S_REFLECT, RT_S_REFRACT, RT_S_REFLECT_REF, RT_S_NODES, RT_S_TOTAL = 8 };
+// *_REF = what the reference would trace: without glossy perturbation it re-traces gr_samples identical reflection
+// rays per hit, and with them their whole subtrees; every ray carries that multiplicity.
+enum { RT_S_PRIMARY = 0, RT_S_SHADOW, RT_S_REFLECT, RT_S_REFRACT, RT_S_NODES, RT_S_SHADOW_REF, RT_S_REFLECT_REF, RT_S_REFRACT_REF, RT_S_TOTAL = 8 };
 
 // kernel launchers (rt_kernels.hip)
 void rt_launch_level_begin(hipStream_t s, const DevWork& w, int level);

@@ -1,0 +1,43 @@
+"""Regenerates the golden fixtures from the compiled, unmodified reference (oracle/_ref/raytracer_ref).
+
+Runs only where /root/reference is mounted (`make -C oracle ref` first).  Outputs are data only:
+  deterministic.npz : uint8 [H,W,3] image per deterministic case of tests/cases.py
+  stochastic.npz    : uint8 [H,W,3] high-sample image per stochastic case
+  config1_1080p.npz : the reference's default render of its own scene.json at 1920x1080
+"""
+import sys
+from concurrent.futures import ProcessPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent))
+import cases  # noqa: E402
+import ref_runner  # noqa: E402
+
+TEX = {p.name: p for p in cases.TEXTURES.glob("*.ppm")}
+
+
+def run(job):
+    scene, flags = job
+    img, secs, _ = ref_runner.run_ref(cases.SCENES[scene](), flags, TEX)
+    assert img.min() >= 0 and img.max() <= 255
+    return cases.case_id(scene, flags), img.astype(np.uint8), secs
+
+
+def main():
+    with ProcessPoolExecutor(max_workers=6) as ex:
+        det = list(ex.map(run, cases.DETERMINISTIC))
+        sto = list(ex.map(run, cases.STOCHASTIC))
+    np.savez_compressed(HERE / "deterministic.npz", **{k: v for k, v, _ in det})
+    np.savez_compressed(HERE / "stochastic.npz", **{k: v for k, v, _ in sto})
+    for k, _, s in det + sto:
+        print(f"{k:60s} {s:8.2f} s")
+    img, secs, _ = ref_runner.run_ref(cases.reference_scene(1920, 1080), [], TEX)
+    np.savez_compressed(HERE / "config1_1080p.npz", image=img.astype(np.uint8), loop_seconds=np.float64(secs))
+    print(f"config1 1080p {secs:.2f} s")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""The N>1 plumbing on CPU: two gloo ranks each hold the tile-major block rt_render_device would produce for
+their shard, rank 0 gathers and re-assembles; the result must be the unsharded image."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import cases
+import oracle
+from raytracer_amd import api
+
+
+def shard_block(img: np.ndarray, rank: int, world: int) -> np.ndarray:
+    """What rank `rank` of `world` would hand to the gather: its tiles in ascending global order, padded."""
+    h, w, _ = img.shape
+    slots, max_tiles, _, _ = api.tile_owner_slots(w, h, world)
+    blk = np.zeros((max_tiles, api.TILE, api.TILE, 3), dtype=np.uint8)
+    for (tx, ty), (o, k) in slots.items():
+        if o != rank:
+            continue
+        y0, x0 = ty * api.TILE, tx * api.TILE
+        t = img[y0:y0 + api.TILE, x0:x0 + api.TILE]
+        blk[k, :t.shape[0], :t.shape[1]] = t
+    return blk.reshape(-1)
+
+
+def _worker(rank: int, world: int, port: int, img: np.ndarray, out_path: str):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from raytracer_amd import dist as rdist
+    import torch.distributed as dist
+    r, w, _ = rdist.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    text = rdist.broadcast_bytes(b"scene-bytes" if rank == 0 else None)
+    assert text == b"scene-bytes"
+    block = torch.from_numpy(shard_block(img, rank, world))
+    gathered = rdist.gather_blocks(block, dst=0)
+    if rank == 0:
+        blocks = [c.numpy() for c in gathered.chunk(world)]
+        np.save(out_path, api.assemble_tiles_numpy(blocks, img.shape[1], img.shape[0]))
+    else:
+        assert gathered is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_and_assemble_world_n(world, tmp_path):
+    img, _ = oracle.render(cases.reference_scene(200, 112), [])     # sizes that are not multiples of the tile
+    img = img.astype(np.uint8)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    out = str(tmp_path / "assembled.npy")
+    mp.spawn(_worker, args=(world, port, img, out), nprocs=world, join=True)
+    assert np.array_equal(np.load(out), img)
+
+
+def test_tile_ownership_is_balanced_and_complete():
+    for (w, h) in [(1920, 1080), (3840, 2160), (200, 112), (31, 33)]:
+        for world in (1, 2, 4, 8):
+            slots, max_tiles, tx_n, ty_n = api.tile_owner_slots(w, h, world)
+            assert len(slots) == tx_n * ty_n
+            counts = np.bincount([o for o, _ in slots.values()], minlength=world)
+            assert counts.max() == max_tiles and counts.max() - counts.min() <= max(1, ty_n)
+            for r in range(world):                       # slot indices are 0..count-1 in ascending tile order
+                ks = [k for (tx, ty), (o, k) in sorted(slots.items(), key=lambda kv: (kv[0][1], kv[0][0])) if o == r]
+                assert ks == list(range(len(ks)))

@@ -1,0 +1,174 @@
+"""Parity of the HIP render path, called through the C ABI (raytracer_amd/librt_amd.so), with the CPU
+restatement (the checker) and with golden images rendered by the compiled reference.
+
+Bar: deterministic flag sets within +-1 LSB per 8-bit channel (in practice bit-exact; the count of differing
+pixels is asserted too); stochastic flag sets >= 40 dB PSNR between two high-sample renders."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import oracle
+from raytracer_amd import api, scenegen as sg
+
+pytestmark = pytest.mark.gpu
+
+DET = np.load(cases.GOLDEN / "deterministic.npz")
+STO = np.load(cases.GOLDEN / "stochastic.npz")
+TOL_LSB = 1                      # per 8-bit channel, deterministic renders
+MAX_DIFFERING_FRACTION = 1e-3    # and at most 0.1 % of the pixels may differ at all
+PSNR_DB = 40.0
+
+
+def psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+
+
+def assert_close_images(img, ref, what):
+    d = np.abs(img.astype(np.int32) - ref.astype(np.int32))
+    differing = (d.max(axis=2) > 0).mean()
+    assert d.max() <= TOL_LSB, f"{what}: max |diff| = {d.max()} LSB, {int((d.max(axis=2) > TOL_LSB).sum())} pixels beyond tolerance"
+    assert differing <= MAX_DIFFERING_FRACTION, f"{what}: {differing:.2%} of the pixels differ"
+
+
+def test_native_library_is_what_runs():
+    assert torch.cuda.is_available()
+    api.lib()
+    assert any("librt_amd.so" in line for line in open("/proc/self/maps"))
+
+
+@pytest.mark.parametrize("scene,flags", cases.DETERMINISTIC, ids=[cases.case_id(s, f) for s, f in cases.DETERMINISTIC])
+def test_deterministic_matches_oracle_and_reference_golden(scene, flags, textures_dir):
+    text = cases.SCENES[scene]()
+    img, st = api.render_scene_text(text, flags, textures_dir)
+    ref, ost = oracle.render(text, flags, textures_dir)
+    assert_close_images(img, ref, "vs oracle")
+    assert_close_images(img, DET[cases.case_id(scene, flags)], "vs reference golden")
+    # ray accounting: the reference-equivalent counts (identical reflection rays and their subtrees counted
+    # gr_samples times, as the reference traces them) equal what the restatement counts while it renders
+    assert st.primary_rays == ost.primary
+    assert (st.shadow_rays_ref, st.reflection_rays_ref, st.refraction_rays_ref) == (ost.shadow, ost.reflection, ost.refraction)
+    if "-r" not in flags and "-rd" not in flags:
+        assert st.shadow_rays == ost.shadow and st.reflection_rays == 0 and st.refraction_rays == 0
+
+
+def test_config1_full_frame_matches_reference_golden():
+    g = np.load(cases.GOLDEN / "config1_1080p.npz")["image"]
+    img, st = api.render_scene_text(cases.reference_scene(1920, 1080), [])
+    assert_close_images(img, g, "config 1 at 1920x1080")
+    assert st.primary_rays == 1920 * 1080
+
+
+@pytest.mark.parametrize("scene,flags", cases.STOCHASTIC, ids=[cases.case_id(s, f) for s, f in cases.STOCHASTIC])
+def test_stochastic_psnr_vs_reference_high_sample_render(scene, flags, textures_dir):
+    img, _ = api.render_scene_text(cases.SCENES[scene](), flags, textures_dir)
+    gold = STO[cases.case_id(scene, flags)]
+    p = psnr(img, gold)
+    assert p >= PSNR_DB, f"PSNR {p:.1f} dB"
+
+
+def test_stochastic_is_reproducible_and_seeded():
+    text = cases.SCENES["ref"]()
+    flags = ["-aa", "-aas", "4", "-ss", "-sss", "4", "-r", "-gr", "-grs", "2"]
+    a, _ = api.render_scene_text(text, flags)
+    b, _ = api.render_scene_text(text, flags)
+    c, _ = api.render_scene_text(text, flags + ["--seed", "7"])
+    assert np.array_equal(a, b)
+    assert not np.array_equal(a, c)
+
+
+def test_identical_reflection_rays_are_traced_once_but_summed_gr_times():
+    """Without -gr the reference traces gr_samples identical reflection rays; tracing one and replaying the
+    float sum must give the same image as the oracle's literal loop for any gr_samples."""
+    text = cases.SCENES["glass"]()
+    for grs in ("1", "3", "16"):
+        img, st = api.render_scene_text(text, ["-rd", "2", "-grs", grs])
+        ref, _ = oracle.render(text, ["-rd", "2", "-grs", grs])
+        assert_close_images(img, ref, f"-grs {grs}")
+        assert st.reflection_rays <= st.reflection_rays_ref
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_render_assembles_to_the_unsharded_image(world, textures_dir):
+    """Full-size property: rendering interleaved tile shards (one context per rank, here all on GPU 0), gathering the
+    blocks and assembling them on the device gives exactly the single-context image, stochastic effects included."""
+    text = cases.reference_scene(1920, 1080)
+    flags = ["-r", "-ss", "-sss", "4", "-aa", "-aas", "2"]
+    cfg, _ = api.parse_args(flags)
+    ls = api.LoadedScene(text, cfg)
+    whole = api.Renderer(0); whole.upload(ls)
+    full, st_full = whole.render(cfg)
+    blocks, rays = [], 0
+    for rank in range(world):
+        r = api.Renderer(0); r.upload(ls); r.set_shard(rank, world)
+        out = torch.empty(r.out_bytes(), dtype=torch.uint8, device="cuda")
+        st = r.render_device(cfg, out.data_ptr(), want_stats=True)
+        rays += st.total_rays()
+        blocks.append(out)
+        r.close()
+    assert rays == st_full.total_rays()
+    gathered = torch.cat(blocks)
+    root = api.Renderer(0); root.upload(ls); root.set_shard(0, world)
+    img = torch.empty(1080 * 1920 * 3, dtype=torch.uint8, device="cuda")
+    root.assemble(gathered.data_ptr(), world, img.data_ptr()); root.synchronize()
+    got = img.cpu().numpy().reshape(1080, 1920, 3)
+    assert np.array_equal(got, full)
+    assert np.array_equal(api.assemble_tiles_numpy([b.cpu().numpy() for b in blocks], 1920, 1080), full)
+    root.close(); whole.close(); ls.close()
+
+
+def test_small_workspace_renders_in_chunks_with_the_same_result():
+    text = cases.reference_scene(640, 360)
+    flags = ["-rd", "3", "-grs", "1", "-ss", "-sss", "4"]
+    big, _ = api.render_scene_text(text, flags)
+    small, st = api.render_scene_text(text, flags, workspace_bytes=8 << 20)
+    assert np.array_equal(big, small)
+
+
+def test_non_power_of_two_shadow_samples_and_many_lights():
+    cams = [sg.camera(res=(160, 90))]
+    lights = [sg.light((4, 1, 6), 500.0), sg.light((-4, -2, 5), 300.0), sg.light((0, 3, 8), 200.0)]
+    m = sg.material((0.7, 0.6, 0.5), (0.2, 0.2, 0.2), 40.0)
+    text = sg.scene_text(cams, lights, [sg.sphere((0, 1, 1), 1.0, m)], [sg.cube((2.5, 2, 0.7), 0.7, m, (0.1, 0.2, 0.3))], [sg.ground(20.0, 0.0, m)])
+    img, st = api.render_scene_text(text, [])
+    ref, ost = oracle.render(text, [])
+    assert_close_images(img, ref, "3 lights, hard shadows")
+    assert st.shadow_rays == ost.shadow
+    a, sa = api.render_scene_text(text, ["-ss", "-sss", "48"])       # 48 is not a power of two: atomic accumulation path
+    b, sb = api.render_scene_text(text, ["-ss", "-sss", "64"])
+    assert sa.shadow_rays == sa.nodes_shaded * 3 * 48
+    assert psnr(a, b) > 35.0
+
+
+def test_empty_and_lightless_scenes():
+    img, st = api.render_scene_text(sg.scene_text([sg.camera(res=(70, 40))], [], [], [], []), [])
+    assert img.shape == (40, 70, 3) and img.max() == 0 and st.primary_rays == 70 * 40
+    m = sg.material((0.8, 0.4, 0.2))
+    text = sg.scene_text([sg.camera(res=(70, 40))], [], [sg.sphere((0, 0, 1.5), 1.0, m)], [], [])
+    for flags in ([], ["-u"]):
+        img, _ = api.render_scene_text(text, flags)
+        ref, _ = oracle.render(text, flags)
+        assert np.array_equal(img.astype(np.int32), ref) and img.max() > 0      # ambient term only
+
+
+def test_error_paths():
+    cfg, _ = api.parse_args([])
+    r = api.Renderer(0)
+    with pytest.raises(api.RtError) as e:
+        r.render(cfg)                                   # nothing uploaded
+    assert e.value.code == -3
+    ls = api.LoadedScene(cases.SCENES["ref"](), cfg)
+    r.upload(ls, with_bvh=False)
+    with pytest.raises(api.RtError) as e:
+        r.render(cfg)                                   # config wants the BVH, none uploaded
+    assert e.value.code == -3
+    cfg_u, _ = api.parse_args(["-u"])
+    img, _ = r.render(cfg_u)
+    assert img.max() > 0
+    bad, _ = api.parse_args(["-aa", "-aas", "0"])
+    with pytest.raises(api.RtError):
+        r.render(bad)
+    with pytest.raises(api.RtError):
+        r.set_shard(3, 2)
+    r.close(); ls.close()

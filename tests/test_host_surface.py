@@ -1,0 +1,161 @@
+"""Host surface (flags, scene text, BVH build, PPM) and the shape of the C ABI. No GPU needed."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+from raytracer_amd import api, scenegen as sg
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    L = api.lib()
+    declared = set()
+    for hdr in ("rt_api.h", "rt_host.h"):
+        text = (ROOT / "include" / hdr).read_text()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", text))
+    assert declared == set(api.API_SYMBOLS) | set(api.HOST_SYMBOLS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    out = subprocess.run(["nm", "-D", "--defined-only", str(api.LIB_PATH)], capture_output=True, text=True).stdout
+    for name in declared:
+        assert re.search(rf"\bT {name}\b", out), f"{name} is not an exported text symbol"
+
+
+def test_struct_sizes_match_the_headers():
+    assert C.sizeof(api.Camera) == 13 * 4
+    assert C.sizeof(api.Material) == 10 * 4
+    assert C.sizeof(api.Sphere) == 17 * 4
+    assert C.sizeof(api.Cube) == 20 * 4
+    assert C.sizeof(api.Plane) == 15 * 4
+    assert C.sizeof(api.BvhNode) == 12 * 4
+    assert C.sizeof(api.Config) == 16 * 4
+
+
+def test_parse_args_defaults_and_flags():
+    cfg, out = api.parse_args([])
+    assert (cfg.soft_shadows, cfg.ss_samples, cfg.glossy_reflect, cfg.gr_samples) == (0, 4, 0, 16)
+    assert (cfg.anti_aliasing, cfg.aa_samples, cfg.textures, cfg.bvh, cfg.reflect_refract_depth) == (0, 4, 0, 1, 0)
+    assert (cfg.dof, cfg.dof_samples, cfg.motion_blur, cfg.mb_samples) == (0, 16, 0, 16)
+    assert abs(cfg.light_radius - 0.25) < 1e-9 and out == "output.ppm"
+    cfg, out = api.parse_args(["-ss", "-sss", "9", "-gr", "-grs", "3", "-aa", "-aas", "5", "-u", "-rd", "4", "-t", "-dof",
+                               "-dofs", "7", "-m", "-mbs", "2", "-o", "x.ppm"])
+    assert (cfg.soft_shadows, cfg.ss_samples, cfg.glossy_reflect, cfg.gr_samples) == (1, 9, 1, 3)
+    assert (cfg.anti_aliasing, cfg.aa_samples, cfg.textures, cfg.bvh, cfg.reflect_refract_depth) == (1, 5, 1, 0, 4)
+    assert (cfg.dof, cfg.dof_samples, cfg.motion_blur, cfg.mb_samples, out) == (1, 7, 1, 2, "x.ppm")
+    # long spellings; -r means depth 1; -dofs only sets the count; "-s" is not a flag of the reference's parser
+    cfg, _ = api.parse_args(["--soft_shadows", "--reflections", "--dof_samples", "3", "-s", "--motion-blur"])
+    assert (cfg.soft_shadows, cfg.reflect_refract_depth, cfg.dof, cfg.dof_samples, cfg.motion_blur) == (1, 1, 0, 3, 1)
+    # same answers as the oracle's restatement of config.cpp
+    for flags in (["-r", "-rd", "3"], ["-rd", "3", "-r"], ["-sss"], ["-aas", "2", "-aa"]):
+        a, _ = api.parse_args(flags, extensions=False)
+        b = oracle.parse_args(flags)
+        assert (a.reflect_refract_depth, a.ss_samples, a.aa_samples, a.anti_aliasing) == \
+               (b.reflectRefractDepth, b.SSsamples, b.AAsamples, b.antiAliasing)
+
+
+def test_scene_parse_matches_file_values():
+    cfg, _ = api.parse_args(["-dof"])
+    ls = api.LoadedScene(cases.reference_scene(), cfg)
+    sc = ls.scene
+    assert (sc.n_lights, sc.n_spheres, sc.n_cubes, sc.n_planes, sc.n_plane_verts) == (1, 1, 1, 1, 4)
+    cam = sc.camera
+    assert list(cam.location) == [0.0, -8.0, 1.5] and cam.res_x == 1920 and cam.res_y == 1080
+    assert cam.aperture == 1.0 and cam.focal_distance == np.float32(7.000012397766113)
+    assert cam.focal_length == np.float32(50.0) / np.float32(1000.0) and cam.sensor_width == np.float32(36.0) / np.float32(1000.0)
+    assert sc.cubes[0].rotation[1] == np.float32(0.40142571926116943) and sc.cubes[0].end[2] == 5.0
+    assert sc.spheres[0].mat.shininess == np.float32(115.19999980926514) and sc.spheres[0].mat.tex_id == -1
+    assert list(sc.planes[0].normal) == [0.0, 0.0, 1.0]
+    ls.close()
+    cfg, _ = api.parse_args([])
+    ls = api.LoadedScene(cases.reference_scene(), cfg)
+    assert ls.scene.camera.aperture == 0.0       # aperture is only read with -dof
+    ls.close()
+
+
+def test_scene_parse_quirks_and_errors():
+    cfg, _ = api.parse_args([])
+    # light numbers are scanned without 'e': "1e3" stops at "1"
+    text = cases.reference_scene().replace('"radiant_intensity": 1000.0', '"radiant_intensity": 1e3')
+    ls = api.LoadedScene(text, cfg)
+    assert ls.scene.lights[0].rad_intensity == 1.0
+    ls.close()
+    # a missing key is an error (the reference throws "Key not found in JSON string")
+    with pytest.raises(api.RtError):
+        api.LoadedScene(cases.reference_scene().replace('"radius"', '"rad"'), cfg)
+    # a missing texture file is an error when -t is on, ignored otherwise
+    tex_scene = sg.glass_scene((64, 36), True)
+    api.LoadedScene(tex_scene, cfg).close()
+    cfg_t, _ = api.parse_args(["-t"])
+    with pytest.raises(api.RtError):
+        api.LoadedScene(tex_scene, cfg_t, "/nonexistent")
+    ls = api.LoadedScene(tex_scene, cfg_t, str(cases.TEXTURES))
+    assert ls.scene.n_textures == 2 and ls.scene.spheres[1].mat.tex_id == 0 and ls.scene.cubes[0].mat.tex_id == 1
+    assert ls.scene.planes[0].mat.tex_id == 0    # checkerboard.ppm is loaded once and shared
+    ls.close()
+
+
+@pytest.mark.parametrize("name,text", [("ref", cases.reference_scene()), ("glass", sg.glass_scene()),
+                                       ("cluster", sg.cluster_scene(16)),
+                                       ("rand", sg.random_scene(300, 3, rmin=0.2, rmax=0.5, moving=True)),
+                                       ("rand2k", sg.random_scene(2000, 5))])
+def test_host_bvh_and_camera_match_oracle_bit_for_bit(name, text):
+    cfg, _ = api.parse_args([])
+    ls = api.LoadedScene(text, cfg)
+    a, b = ls.bvh_nodes(), oracle.bvh_dump(text, cap=8192)[:, :11]
+    assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    bv = ls.bvh()
+    n_prims = ls.scene.n_planes + ls.scene.n_cubes + ls.scene.n_spheres
+    assert bv.n_prim_ids == n_prims      # every primitive sits in exactly one leaf
+    for x, y in [(0, 0), (960, 540), (17.25, 5.5), (1919, 1079)]:
+        r1, r2 = api.camera_ray(ls.scene.camera, x, y), oracle.camera_ray(text, x, y)
+        assert np.array_equal(r1.view(np.uint32), r2.view(np.uint32))
+    ls.close()
+
+
+def test_empty_scene_builds():
+    text = sg.scene_text([sg.camera(res=(32, 32))], [], [], [], [])
+    cfg, _ = api.parse_args([])
+    ls = api.LoadedScene(text, cfg)
+    assert ls.bvh().n_nodes == 1 and ls.bvh().n_prim_ids == 0
+    ls.close()
+
+
+def test_ppm_reader_p3_p6_shift_and_writer(tmp_path):
+    # P6: the separator byte after maxval becomes the first red value, so pure red turns green (and so on)
+    p6 = tmp_path / "red.ppm"
+    p6.write_bytes(b"P6\n2 2\n255\n" + bytes([255, 0, 0] * 4))
+    img = api.read_ppm(str(p6))
+    assert img.shape == (2, 2, 3)
+    assert img[0, 0].tolist() == [10, 255, 0] and img[0, 1].tolist() == [0, 255, 0] and img[1, 1].tolist() == [0, 255, 0]
+    p3 = tmp_path / "a.ppm"
+    p3.write_text("P3\n2 1\n255\n1 2 3\n4 5 6\n")
+    assert api.read_ppm(str(p3)).reshape(-1).tolist() == [1, 2, 3, 4, 5, 6]
+    with pytest.raises(api.RtError):
+        api.read_ppm(str(tmp_path / "missing.ppm"))
+    bad = tmp_path / "bad.ppm"; bad.write_text("P5\n1 1\n255\n0")
+    with pytest.raises(api.RtError):
+        api.read_ppm(str(bad))
+    # writer: "P3\nW H\nmax\n", "r g b " per pixel, "\n" per row
+    out = tmp_path / "o.ppm"
+    api.write_ppm(str(out), np.array([[[0, 9, 10], [99, 100, 255]]], dtype=np.uint8))
+    assert out.read_text() == "P3\n2 1\n255\n0 9 10 99 100 255 \n"
+    # the committed textures read like the oracle reads them
+    for name in ("checkerboard.ppm", "tex2.ppm"):
+        a = api.read_ppm(str(cases.TEXTURES / name))
+        assert a.min() >= 0 and a.max() <= 255 and a.shape[2] == 3
+
+
+def test_render_calls_fail_loudly_without_a_gpu_or_scene():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(api.RtError):
+        api.Renderer(0)

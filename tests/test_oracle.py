@@ -1,0 +1,94 @@
+"""The CPU restatement (oracle/) against the reference: committed golden images rendered by the compiled,
+unmodified reference binary, known-answer values measured on it, and - where the binary is present - live runs."""
+import numpy as np
+import pytest
+
+import cases
+import oracle
+import ref_runner
+
+DET = np.load(cases.GOLDEN / "deterministic.npz")
+STO = np.load(cases.GOLDEN / "stochastic.npz")
+
+
+@pytest.mark.parametrize("scene,flags", cases.DETERMINISTIC, ids=[cases.case_id(s, f) for s, f in cases.DETERMINISTIC])
+def test_oracle_matches_reference_golden_deterministic(scene, flags, textures_dir):
+    img, _ = oracle.render(cases.SCENES[scene](), flags, textures_dir)
+    gold = DET[cases.case_id(scene, flags)].astype(np.int32)
+    assert img.shape == gold.shape
+    assert np.array_equal(img, gold), f"{(img != gold).any(axis=2).sum()} pixels differ"
+
+
+# The restatement consumes rand() in the reference's order, so even sampled images are byte-identical
+# (glibc generator, never seeded = srand(1)). The two cheapest cases keep the CPU suite short.
+@pytest.mark.parametrize("scene,flags", [cases.STOCHASTIC[1], cases.STOCHASTIC[4]],
+                         ids=[cases.case_id(*cases.STOCHASTIC[1]), cases.case_id(*cases.STOCHASTIC[4])])
+def test_oracle_matches_reference_golden_stochastic(scene, flags, textures_dir):
+    img, _ = oracle.render(cases.SCENES[scene](), flags, textures_dir, rand_seed=1)
+    gold = STO[cases.case_id(scene, flags)].astype(np.int32)
+    assert np.array_equal(img, gold)
+
+
+def test_oracle_config1_1080p_matches_reference():
+    g = np.load(cases.GOLDEN / "config1_1080p.npz")
+    img, st = oracle.render(cases.reference_scene(1920, 1080), [])
+    assert np.array_equal(img, g["image"].astype(np.int32))
+    assert st.primary == 1920 * 1080
+    assert 600_000 < st.shadow < 700_000     # the reference traces about 647 000 shadow rays on this frame
+
+
+def test_known_answers_measured_on_the_reference():
+    text = cases.reference_scene(1920, 1080)
+    nodes = oracle.bvh_dump(text)
+    assert len(nodes) == 17                                   # 17 nodes
+    leaves = nodes[(nodes[:, 6] == 0) & (nodes[:, 7] == 0)]
+    assert len(leaves) == 2 and set(leaves[:, 11]) == {8.0}   # two leaves, both at depth 8
+    np.testing.assert_array_equal(nodes[0, :6], np.float32([-5, -5, -1.31123602, 5, 19, 6.3112359]))
+    left = nodes[1]
+    np.testing.assert_array_equal(left[:6], np.float32([-5, -5, -1.31123602, 5, 5, 6.3112359]))
+    assert (left[6], left[7]) == (0.0, 1.0)                   # right-only chain down to the {plane, cube} leaf
+    sphere_leaf = leaves[leaves[:, 10] == 1][0]
+    np.testing.assert_array_equal(sphere_leaf[:6], np.float32([1, 17, 2, 3, 19, 4]))
+    r = oracle.camera_ray(text, 960, 540)
+    np.testing.assert_array_equal(r, np.float32([0, -8, 1.5, 0.000187497135, 1, -0.000222171933]))
+    r = oracle.camera_ray(text, 0, 0)
+    np.testing.assert_array_equal(r[3:], np.float32([-0.330261916, 0.91787225, 0.220085412]))
+
+
+def test_bvh_result_is_last_leaf_not_closest(textures_dir):
+    """Two spheres on one line of sight, far one in the later leaf: the BVH render shows the far sphere where
+    they overlap, the unaccelerated render the near one."""
+    from raytracer_amd import scenegen as sg
+    red = sg.material((0.9, 0.0, 0.0), (0, 0, 0), 10.0)
+    blue = sg.material((0.0, 0.0, 0.9), (0, 0, 0), 10.0)
+    text = sg.scene_text([sg.camera(res=(96, 54))], [sg.light((0, -6, 4), 800.0)],
+                         [sg.sphere((0.0, 0.0, 1.5), 1.0, red), sg.sphere((0.3, 6.0, 1.6), 2.5, blue)], [], [])
+    a, _ = oracle.render(text, [])
+    b, _ = oracle.render(text, ["-u"])
+    centre_a, centre_b = a[27, 48], b[27, 48]
+    assert centre_b[0] > centre_b[2]          # true closest hit: red sphere in front
+    assert centre_a[2] > centre_a[0]          # BVH: last leaf (the far, blue sphere) wins
+    assert (a != b).any(axis=2).sum() > 50
+
+
+def test_hard_shadow_has_no_distance_limit():
+    """An occluder BEYOND the light still shadows (the slab test overwrites tMax)."""
+    from raytracer_amd import scenegen as sg
+    grey = sg.material((0.6, 0.6, 0.6), (0, 0, 0), 10.0)
+    base = dict(cams=[sg.camera(location=(0, -8, 3), gaze=(0, 1, -0.3), res=(96, 54))], lights=[sg.light((0, 0, 2.0), 300.0)])
+    plain = sg.scene_text(base["cams"], base["lights"], [], [], [sg.ground(12.0, 0.0, grey)])
+    occluded = sg.scene_text(base["cams"], base["lights"], [sg.sphere((0, 0, 6.0), 1.5, grey)], [], [sg.ground(12.0, 0.0, grey)])
+    a, _ = oracle.render(plain, [])
+    b, _ = oracle.render(occluded, [])
+    darker = (b.sum(axis=2) < a.sum(axis=2)) & (a.sum(axis=2) > 0)
+    assert darker.sum() > 20
+
+
+@pytest.mark.skipif(not ref_runner.have_ref(), reason="reference binary not built (no /root/reference on this machine)")
+@pytest.mark.parametrize("flags", [[], ["-u", "-r", "-grs", "2", "-ss", "-m", "-mbs", "2"], ["-aa", "-aas", "2", "-dof", "-dofs", "2", "-r", "-gr", "-grs", "3"]])
+def test_oracle_matches_live_reference_binary(flags, textures_dir):
+    text = cases.reference_scene(160, 90)
+    tex = {p.name: p for p in cases.TEXTURES.glob("*.ppm")}
+    ref, _, _ = ref_runner.run_ref(text, flags, tex)
+    img, _ = oracle.render(text, flags, textures_dir, rand_seed=1)
+    assert np.array_equal(img, ref)

@@ -21,7 +21,7 @@ def main():
         npx = int((d.max(axis=2) > 0).sum()); mx = int(d.max())
         worst = max(worst, mx)
         print(f"{cases.case_id(scene, flags):40s} maxdiff {mx:3d} px!=0 {npx:6d} gt1 {(d.max(axis=2) > 1).sum():5d} "
-              f"rays gpu {st.total_rays_ref()} orc {ost.total_rays()}  gpu {st.ms_total:.2f} ms wall {t1:.2f}s", flush=True)
+              f"rays(ref-equiv) gpu {st.total_rays_ref()} orc {ost.total_rays()} traced {st.total_rays()}  gpu {st.ms_total:.2f} ms wall {t1:.2f}s", flush=True)
     print("worst", worst)
 
 if __name__ == "__main__":
