@@ -45,11 +45,12 @@ BYTES_PER_SHADOW_RAY = 72       # shadow-ray record 32 B written + read, result 
 BYTES_PER_SHADED_HIT = 32 + 64 + 48   # hit-tree node 16 B written + read, one primitive record, one material
 
 
-def roofline(st: api.Stats) -> dict:
+def roofline(st: api.Stats, workload: str) -> dict:
     """Per-kernel achieved rate from the per-stage HIP-event times of one profiled frame."""
-    extend_rays = st.primary_rays + st.reflection_rays + st.refraction_rays
     kernels = {
-        "k_extend": dict(units=extend_rays, bytes_per_unit=BYTES_PER_EXTEND_RAY, ms=st.ms_extend, launches=st.launches_extend),
+        "k_extend<true>": dict(units=st.primary_rays, bytes_per_unit=BYTES_PER_EXTEND_RAY, ms=st.ms_extend_primary, launches=st.launches_extend_primary),
+        "k_extend<false>": dict(units=st.reflection_rays + st.refraction_rays, bytes_per_unit=BYTES_PER_EXTEND_RAY,
+                                ms=st.ms_extend_secondary, launches=st.launches_extend_secondary),
         "k_shadow": dict(units=st.shadow_rays, bytes_per_unit=BYTES_PER_SHADOW_RAY, ms=st.ms_shadow, launches=st.launches_shadow),
         "k_shade": dict(units=st.nodes_shaded, bytes_per_unit=BYTES_PER_SHADED_HIT, ms=st.ms_shade, launches=st.launches_shade),
     }
@@ -60,8 +61,14 @@ def roofline(st: api.Stats) -> dict:
         k["Grays_or_Ghits_per_s"] = (k["units"] / 1e9) / (k["ms"] / 1e3) if k["ms"] > 0 else 0.0
     dom = max(kernels, key=lambda n: kernels[n]["ms"])
     d = kernels[dom]
+    traffic = None
+    tf = ROOT / "profiles" / "traffic_latest.json"
+    if tf.exists():                    # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh)
+        t = json.loads(tf.read_text())
+        if t.get("workload") == workload and dom in t.get("kernels", {}):
+            traffic = t["kernels"][dom]["hbm_bytes_per_launch"]
     return {"bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["GBps"] / HBM_PEAK_GBS,
-            "traffic": None, "kernel": dom, "avg_launch_ms": d["avg_launch_ms"], "bytes_per_launch": d["bytes_per_launch"],
+            "traffic": traffic, "kernel": dom, "avg_launch_ms": d["avg_launch_ms"], "bytes_per_launch": d["bytes_per_launch"],
             "by_kernel": kernels,
             "note": "scene.json has 3 primitives: BVH nodes and primitive records are served from LDS/L2, HBM carries only the "
                     "ray queues and the hit tree, and the kernels are bound by VALU work (IEEE divides, double-precision "
@@ -73,13 +80,13 @@ def cpu_baseline(workload: dict) -> dict:
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle
     import ref_runner
-    w, h = 48, 27
+    w, h = 800, 450
     text = cases.reference_scene(w, h)
     flags = workload["flags"]
     _, ost = oracle.render(text, flags, str(cases.TEXTURES))          # counts the rays the reference's code path traces
     rays = ost.total_rays()
     out = {"unit": "rays/s", "cores": 1,
-           "sample": f"scene.json at {w}x{h} ({w*h} of 2073600 pixels), flags {' '.join(flags)}, {rays} rays "
+           "sample": f"scene.json at {w}x{h} ({w*h} of 2073600 pixels, same camera and flags), flags {' '.join(flags)}, {rays} rays "
                      f"(the reference re-traces its 16 identical reflection rays per hit; all are counted)"}
     if ref_runner.have_ref():
         tex = {p.name: p for p in cases.TEXTURES.glob("*.ppm")}
@@ -121,7 +128,11 @@ def main():
     r = api.Renderer(local, workspace_bytes=16 << 30)
     r.upload(ls, with_bvh=bool(cfg.bvh))
     r.set_shard(rank, world)
-    stream = torch.cuda.current_stream(dev)
+    # Everything of a step runs on one explicit side stream: the render kernels, the RCCL gather (torch orders its
+    # communication stream against the current stream) and the timing events.
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     r.set_stream(stream.cuda_stream)
 
     block = torch.empty(r.out_bytes(), dtype=torch.uint8, device=dev)
@@ -135,7 +146,10 @@ def main():
                 r.assemble(gathered.data_ptr(), world, image.data_ptr())
         return None
 
-    # ray counts (identical every frame: the generator is counter based)
+    # Ray counts (identical every frame: the generator is counter based) and per-kernel device times.  The profiled
+    # frame is enqueued behind four ordinary ones so that the GPU, not the host, paces it.
+    for _ in range(4):
+        r.render_device(cfg, block.data_ptr())
     st = r.render_device(cfg, block.data_ptr(), want_stats=True)
     rays_local = torch.tensor([st.primary_rays, st.shadow_rays, st.reflection_rays, st.refraction_rays,
                                st.shadow_rays_ref + st.reflection_rays_ref + st.refraction_rays_ref, st.nodes_shaded],
@@ -182,7 +196,7 @@ def main():
                        "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3],
                                           "hits_shaded": tot[5], "as_the_reference_would_trace_them": tot[0] + tot[4]},
                        "lit_fraction": lit},
-            "roofline": roofline(st),
+            "roofline": roofline(st, args.workload),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl)

@@ -160,11 +160,11 @@ typedef struct rt_stats {
     uint64_t reflection_rays_ref;
     uint64_t refraction_rays_ref;
     uint64_t batches;             /* pipeline passes (one per sample index per pixel chunk) */
-    uint64_t launches_extend, launches_shadow, launches_shade;
+    uint64_t launches_extend_primary, launches_extend_secondary, launches_shadow, launches_shade;
     double   ms_total;            /* rt_render*: enqueue -> results ready, host wall clock */
     /* device time per stage, summed over the frame, from HIP events on the render stream; filled only when
        the frame has at most 64 batches (0 otherwise) */
-    double   ms_extend, ms_shadow, ms_shade, ms_other;
+    double   ms_extend_primary, ms_extend_secondary, ms_shadow, ms_shade, ms_other;
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

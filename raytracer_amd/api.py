@@ -86,9 +86,10 @@ class Stats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("reflection_rays", C.c_uint64),
                 ("refraction_rays", C.c_uint64), ("nodes_shaded", C.c_uint64), ("shadow_rays_ref", C.c_uint64),
                 ("reflection_rays_ref", C.c_uint64), ("refraction_rays_ref", C.c_uint64), ("batches", C.c_uint64),
-                ("launches_extend", C.c_uint64), ("launches_shadow", C.c_uint64), ("launches_shade", C.c_uint64),
-                ("ms_total", C.c_double), ("ms_extend", C.c_double), ("ms_shadow", C.c_double), ("ms_shade", C.c_double),
-                ("ms_other", C.c_double)]
+                ("launches_extend_primary", C.c_uint64), ("launches_extend_secondary", C.c_uint64),
+                ("launches_shadow", C.c_uint64), ("launches_shade", C.c_uint64),
+                ("ms_total", C.c_double), ("ms_extend_primary", C.c_double), ("ms_extend_secondary", C.c_double),
+                ("ms_shadow", C.c_double), ("ms_shade", C.c_double), ("ms_other", C.c_double)]
 
     def total_rays(self) -> int:
         return self.primary_rays + self.shadow_rays + self.reflection_rays + self.refraction_rays

@@ -109,6 +109,7 @@ struct rt_ctx {
     DevBuf<unsigned long long> stats;
     DevBuf<unsigned char> out_tmp;
     unsigned long long last_batches = 0;
+    std::vector<hipEvent_t> event_pool;
 
     int fail(int code, const char* fmt, ...) {
         char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -165,6 +166,7 @@ void rt_destroy(rt_ctx* c) {
     for (auto* b : f4s) b->release();
     c->d_leaves.release(); c->d_tex_desc.release(); c->d_local_tiles.release(); c->n_uv.release(); c->n_pix.release();
     c->link.release(); c->ctr.release(); c->shadow.release(); c->stats.release(); c->out_tmp.release();
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -437,33 +439,40 @@ int rt_set_shard(rt_ctx* c, int32_t rank, int32_t world) {
 int32_t rt_local_tiles(const rt_ctx* c) { return c ? (int32_t)c->local_tiles.size() : 0; }
 int32_t rt_max_tiles_per_rank(const rt_ctx* c) { return c ? c->max_tiles : 0; }
 
-// Per-stage device timing of one frame: an event pair around every launch (only used when the caller asked for
-// statistics and the frame is short enough for that to be cheap).
+// Per-stage device timing of one frame: an event pair around every launch, taken from a pool that lives in the
+// context (no event is created while a frame is being enqueued once the pool is warm).  Only used when the caller
+// asked for statistics and the frame is short enough for that to be cheap.
+enum { ST_EXTEND_PRIMARY = 0, ST_EXTEND_SECONDARY = 1, ST_SHADOW = 2, ST_SHADE = 3, ST_OTHER = 4, ST_COUNT = 5 };
 struct StageTimer {
-    struct Span { hipEvent_t a, b; int stage; };
+    struct Span { int a, b; int stage; };
     std::vector<Span> spans;
+    std::vector<hipEvent_t>* pool = nullptr;
+    size_t used = 0;
     hipStream_t s = nullptr;
     bool on = false;
-    unsigned long long launches[4] = { 0, 0, 0, 0 };
+    unsigned long long launches[ST_COUNT] = { 0, 0, 0, 0, 0 };
+    int take() {
+        if (used == pool->size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return -1; pool->push_back(e); }
+        return (int)used++;
+    }
+    void reserve(size_t n) { while (on && pool->size() < n) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; break; } pool->push_back(e); } }
     void begin(int stage) {
         launches[stage]++;
         if (!on) return;
-        Span sp{}; sp.stage = stage;
-        if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) { on = false; return; }
-        (void)hipEventRecord(sp.a, s); spans.push_back(sp);
+        Span sp{}; sp.stage = stage; sp.a = take(); sp.b = take();
+        if (sp.a < 0 || sp.b < 0) { on = false; return; }
+        (void)hipEventRecord((*pool)[(size_t)sp.a], s); spans.push_back(sp);
     }
-    void end() { if (on && !spans.empty()) (void)hipEventRecord(spans.back().b, s); }
-    void collect(double ms[4]) {
-        for (int i = 0; i < 4; ++i) ms[i] = 0.0;
+    void end() { if (on && !spans.empty()) (void)hipEventRecord((*pool)[(size_t)spans.back().b], s); }
+    void collect(double ms[ST_COUNT]) {
+        for (int i = 0; i < ST_COUNT; ++i) ms[i] = 0.0;
         for (auto& sp : spans) {
             float t = 0.0f;
-            if (on && hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) ms[sp.stage] += t;
-            (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);
+            if (on && hipEventElapsedTime(&t, (*pool)[(size_t)sp.a], (*pool)[(size_t)sp.b]) == hipSuccess) ms[sp.stage] += t;
         }
-        spans.clear();
+        spans.clear(); used = 0;
     }
 };
-enum { ST_EXTEND = 0, ST_SHADOW = 1, ST_SHADE = 2, ST_OTHER = 3 };
 
 // Enqueue one frame.  out_dev: device buffer in the layout rt_render_device documents.
 static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev, bool want_stats_zero, StageTimer* tm) {
@@ -514,9 +523,22 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     if (B >= RT_TILE_PIX) B -= B % RT_TILE_PIX; else B -= B % 64;
     if (B < 64) return c->fail(RT_ERR_CAPACITY, "workspace of %llu bytes cannot hold one wavefront of samples at depth %d with fan-out %lld",
                                (unsigned long long)c->workspace_limit, D, k);
-    const size_t cap_nodes = (size_t)((double)B * nodes_per) + 64;
-    const size_t cap_links = (size_t)((double)B * links_per) + 64;
+    // Per-level regions of the node and link arenas: level d holds at most B * k^d hits / rays.
+    std::vector<long long> node_off((size_t)D + 3, 0), link_off((size_t)D + 3, 0);
+    {
+        double per = 1.0;
+        for (int d = 0; d <= D; ++d) {
+            long long cap = (long long)((double)B * per) + 64;
+            node_off[(size_t)d + 1] = node_off[(size_t)d] + cap;
+            if (d >= 1) link_off[(size_t)d + 1] = link_off[(size_t)d] + cap;
+            per *= (double)k;
+        }
+        link_off[(size_t)D + 2] = link_off[(size_t)D + 1];
+    }
+    const size_t cap_nodes = (size_t)node_off[(size_t)D + 1];
+    const size_t cap_links = (size_t)link_off[(size_t)D + 1] + 64;
     const size_t cap_rays = k > 0 ? (size_t)((double)B * widest) + 64 : 64;
+    if (cap_nodes > 0x7fffffffull || cap_links > 0x7fffffffull) return c->fail(RT_ERR_CAPACITY, "batch too large for 32-bit node indices");
 
     hipStream_t s = c->stream;
     RT_HIP(c, hipSetDevice(c->device));
@@ -538,34 +560,31 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     for (int q = 0; q < 2; ++q) { w.q_a[q] = c->q_a[q].p; w.q_b[q] = c->q_b[q].p; }
     w.n_a = c->n_a.p; w.n_b = c->n_b.p; w.n_c = c->n_c.p; w.n_uv = c->n_uv.p; w.n_col = c->n_col.p; w.n_pix = c->n_pix.p;
     w.shadow = c->shadow.p; w.link = c->link.p; w.accum = c->accum.p; w.ctr = c->ctr.p; w.stats = c->stats.p;
-    w.cap_nodes = (unsigned)std::min<size_t>(cap_nodes, 0x7fffffffu);
-    w.cap_rays = (unsigned)std::min<size_t>(cap_rays, 0x7fffffffu);
-    w.cap_links = (unsigned)std::min<size_t>(cap_links, 0x7fffffffu);
+    w.cap_nodes = (unsigned)cap_nodes;
+    for (int d = 0; d <= D + 2 && d < RT_MAX_LEVELS; ++d) { w.node_off[d] = (int)node_off[(size_t)std::min(d, D + 1)]; w.link_off[d] = (int)link_off[(size_t)d]; }
 
     RT_HIP(c, hipMemsetAsync(c->accum.p, 0, (size_t)n_slots * sizeof(float4), s));
-    RT_HIP(c, hipMemsetAsync(c->ctr.p, 0, RT_C_TOTAL * sizeof(int), s));
     if (want_stats_zero) RT_HIP(c, hipMemsetAsync(c->stats.p, 0, RT_S_TOTAL * sizeof(unsigned long long), s));
 
     const int max_grid = 2048;       // 256 CUs x 8 workgroups: enough to fill the chip, grid-stride beyond that
     unsigned long long batches = 0;
-    StageTimer local_tm; if (!tm) tm = &local_tm;
+    StageTimer local_tm; if (!tm) { tm = &local_tm; tm->pool = &c->event_pool; }
     tm->s = s;
     const unsigned long long n_batches = (unsigned long long)((n_slots + B - 1) / B) * (unsigned long long)S;
     if (n_batches > 64) tm->on = false;
+    tm->reserve((size_t)n_batches * (size_t)(2 * D + 3) * 2 + 2);
     for (long long begin = 0; begin < n_slots; begin += B) {
         const int count = (int)std::min<long long>(B, n_slots - begin);
         f.pix_begin = (int)begin; f.pix_count = count;
         const int grid0 = std::max(1, std::min(max_grid, (count + RT_BLOCK - 1) / RT_BLOCK));
         for (int smp = 0; smp < S; ++smp) {
             f.sample = smp;
-            RT_HIP(c, hipMemsetAsync(c->ctr.p, 0, 2 * sizeof(int), s));     // RT_C_NODE, RT_C_LINK
+            RT_HIP(c, hipMemsetAsync(c->ctr.p, 0, RT_C_TOTAL * sizeof(int), s));   // counters and level starts of the batch
             for (int level = 0; level <= D; ++level) {
-                rt_launch_level_begin(s, w, level);
-                tm->begin(ST_EXTEND);
+                tm->begin(level == 0 ? ST_EXTEND_PRIMARY : ST_EXTEND_SECONDARY);
                 rt_launch_extend(s, c->scene, f, w, level, level == 0 ? grid0 : max_grid);
                 tm->end();
             }
-            rt_launch_level_begin(s, w, D + 1);
             if (!grouped) RT_HIP(c, hipMemsetAsync(c->shadow.p, 0, cap_nodes * (size_t)std::max(L, 1) * sizeof(float), s));
             if (L > 0) { tm->begin(ST_SHADOW); rt_launch_shadow(s, c->scene, f, w, max_grid); tm->end(); }
             for (int level = D; level >= 0; --level) {
@@ -591,9 +610,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
 }
 
 static int finish_stats(rt_ctx* c, rt_stats* st, double ms, StageTimer* tm) {
-    int ctr[4] = { 0, 0, 0, 0 };
     unsigned long long hs[RT_S_TOTAL];
-    RT_HIP(c, hipMemcpyAsync(ctr, c->ctr.p, sizeof ctr, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipMemcpyAsync(hs, c->stats.p, sizeof hs, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     if (st) {
@@ -602,20 +619,22 @@ static int finish_stats(rt_ctx* c, rt_stats* st, double ms, StageTimer* tm) {
         st->refraction_rays = hs[RT_S_REFRACT]; st->nodes_shaded = hs[RT_S_NODES];
         st->shadow_rays_ref = hs[RT_S_SHADOW_REF]; st->reflection_rays_ref = hs[RT_S_REFLECT_REF]; st->refraction_rays_ref = hs[RT_S_REFRACT_REF];
         st->batches = c->last_batches; st->ms_total = ms;
-        double sm[4]; tm->collect(sm);
-        st->ms_extend = sm[ST_EXTEND]; st->ms_shadow = sm[ST_SHADOW]; st->ms_shade = sm[ST_SHADE]; st->ms_other = sm[ST_OTHER];
-        st->launches_extend = tm->launches[ST_EXTEND]; st->launches_shadow = tm->launches[ST_SHADOW]; st->launches_shade = tm->launches[ST_SHADE];
-    } else { double sm[4]; tm->collect(sm); }
-    if (ctr[RT_C_ERR]) return c->fail(RT_ERR_CAPACITY, "a work buffer overflowed during the frame; the image is incomplete");
+        double sm[ST_COUNT]; tm->collect(sm);
+        st->ms_extend_primary = sm[ST_EXTEND_PRIMARY]; st->ms_extend_secondary = sm[ST_EXTEND_SECONDARY];
+        st->ms_shadow = sm[ST_SHADOW]; st->ms_shade = sm[ST_SHADE]; st->ms_other = sm[ST_OTHER];
+        st->launches_extend_primary = tm->launches[ST_EXTEND_PRIMARY]; st->launches_extend_secondary = tm->launches[ST_EXTEND_SECONDARY];
+        st->launches_shadow = tm->launches[ST_SHADOW]; st->launches_shade = tm->launches[ST_SHADE];
+    } else { double sm[ST_COUNT]; tm->collect(sm); }
+    if (hs[RT_S_ERR]) return c->fail(RT_ERR_CAPACITY, "a work buffer overflowed during the frame; the image is incomplete");
     return RT_OK;
 }
 
 int rt_render_device(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev, rt_stats* stats) {
     if (!c || !cfg || !rgb_out_dev) return RT_ERR_ARG;
     auto t0 = std::chrono::steady_clock::now();
-    StageTimer tm; tm.on = stats != nullptr;
+    StageTimer tm; tm.on = stats != nullptr; tm.pool = &c->event_pool;
     int rc = enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true, &tm);
-    if (rc != RT_OK) { double sm[4]; (void)hipStreamSynchronize(c->stream); tm.collect(sm); return rc; }
+    if (rc != RT_OK) { double sm[ST_COUNT]; (void)hipStreamSynchronize(c->stream); tm.collect(sm); return rc; }
     if (!stats) return RT_OK;
     RT_HIP(c, hipStreamSynchronize(c->stream));
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -630,9 +649,9 @@ int rt_render(rt_ctx* c, const rt_config* cfg, uint8_t* rgb_out, rt_stats* stats
                                       : (size_t)((int)c->camera.res_x) * (size_t)((int)c->camera.res_y) * 3;
     if (bytes > c->out_tmp.n) { RT_HIP(c, hipStreamSynchronize(c->stream)); RT_HIP(c, c->out_tmp.resize(bytes)); }
     auto t0 = std::chrono::steady_clock::now();
-    StageTimer tm; tm.on = stats != nullptr;
+    StageTimer tm; tm.on = stats != nullptr; tm.pool = &c->event_pool;
     int rc = enqueue_frame(c, cfg, c->out_tmp.p, true, &tm);
-    if (rc != RT_OK) { double sm[4]; (void)hipStreamSynchronize(c->stream); tm.collect(sm); return rc; }
+    if (rc != RT_OK) { double sm[ST_COUNT]; (void)hipStreamSynchronize(c->stream); tm.collect(sm); return rc; }
     RT_HIP(c, hipStreamSynchronize(c->stream));
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     RT_HIP(c, hipMemcpy(rgb_out, c->out_tmp.p, bytes, hipMemcpyDeviceToHost));

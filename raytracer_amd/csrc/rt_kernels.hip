@@ -43,11 +43,12 @@ DEVI float powf_ref(float x, float y) { return (float)pow((double)x, (double)y);
 
 struct Ray { V3 o, d; float time; };
 
-// Philox-4x32-10 counter-based generator: value = f(counter, key), no state, any lane can draw any number.
+// Philox-4x32 counter-based generator (7 rounds, the shortest variant that passes BigCrush):
+// value = f(counter, key), no state, any lane can draw any number.
 DEVI uint4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < 7; ++r) {
         uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0, hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
@@ -59,12 +60,15 @@ DEVI float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   
 DEVI uint32_t mix32(uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
 enum { STREAM_AA = 1, STREAM_DOF = 2, STREAM_MB = 3, STREAM_SHADOW = 4, STREAM_GLOSSY = 5 };
 
-// raytracer.cpp:634-644 on three uniforms
+// raytracer.cpp:634-644 on three uniforms: theta = 2 pi u, phi = acos(2v-1), r = cbrt(w).  Sampling code, judged by
+// its distribution: cos(phi) = 2v-1 and sin(phi) = sqrt(1-cos^2) replace the acos/sin/cos round trip, sin/cos(2 pi u)
+// come from the hardware instructions that take their argument in revolutions, cbrt is exp2(log2(w)/3).
 DEVI V3 unit_sphere(float u, float v, float w) {
-    float theta = (float)((double)(u * 2.0f) * M_PI);
-    float phi = acosf(2.0f * v - 1.0f);
-    float r = cbrtf(w);
-    return mk(r * sinf(phi) * cosf(theta), r * sinf(phi) * sinf(theta), r * cosf(phi));
+    float ct = __builtin_amdgcn_cosf(u), st = __builtin_amdgcn_sinf(u);
+    float cp = 2.0f * v - 1.0f;
+    float sp = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - cp * cp));
+    float r = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(w) * (1.0f / 3.0f));
+    return mk(r * sp * ct, r * sp * st, r * cp);
 }
 
 // raytracer.cpp:647-668: z and phi come from 1000-level quantised draws; basis from (0,1,0) x dir
@@ -139,6 +143,18 @@ DEVI bool cube_test(const float4* __restrict__ rec, const Ray& r, bool mb, bool 
     V3 loc = mk(w0.x, w0.y, w0.z);
     if (mb) loc = mk(lerp_ref(w0.x, w1.x, r.time), lerp_ref(w0.y, w1.y, r.time), lerp_ref(w0.z, w1.z, r.time));
     float scale = w0.w, inv = w1.w;
+    if (!FULL) {
+        // Cheap certain-miss test before the exact one: the line's distance from the cube centre against the
+        // circumscribed sphere.  The exact test treats a direction component below 1e-5 as "inside that slab
+        // forever", so a reported hit can lie outside the true cube by up to 1e-5 x distance travelled; the
+        // radius is inflated for that and by 1 %, and the squared distance is given slack for cancellation.
+        // NaNs fail the comparison and fall through to the exact test.
+        V3 l = loc - r.o;
+        float D2 = dot(l, l), tca = dot(l, r.d);
+        float as = fabsf(scale);
+        float R = as * 1.7495f + 2e-5f * (__builtin_amdgcn_sqrtf(D2) + 3.5f * as);
+        if (D2 - tca * tca > R * R + 1e-5f * D2) return false;
+    }
     V3 o = rot_inv(r.o - loc, w4, w5);
     V3 d = rot_inv(r.d, w4, w5);
     V3 lo = o * inv;
@@ -256,7 +272,7 @@ DEVI bool plane_test(const float4* __restrict__ rec, const float4* __restrict__ 
 
 // aabb.cpp:31-63: true divisions, ">= 0" picks the near/far plane (so -0.0 takes the positive branch), and the
 // incoming range is ignored.
-DEVI bool slab(const Ray& r, float4 a, float4 b) {
+DEVI bool slab_exact(const Ray& r, float4 a, float4 b) {
     float tminx, tmaxx, tminy, tmaxy, tminz, tmaxz;
     if (r.d.x >= 0) { tminx = (a.x - r.o.x) / r.d.x; tmaxx = (b.x - r.o.x) / r.d.x; }
     else            { tminx = (b.x - r.o.x) / r.d.x; tmaxx = (a.x - r.o.x) / r.d.x; }
@@ -267,6 +283,24 @@ DEVI bool slab(const Ray& r, float4 a, float4 b) {
     float tMin = smax(tminx, smax(tminy, tminz));
     float tMax = smin(tmaxx, smin(tmaxy, tmaxz));
     return tMin <= tMax;
+}
+
+// Same decision as slab_exact at a third of the instructions: quotients by reciprocal-multiply (each within
+// 2.5 ulp of the correctly rounded quotient), the decision taken only when the two bounds are further apart than
+// that error allows; anything closer, and any zero / denormal / huge / NaN direction component, goes to slab_exact.
+DEVI bool slab(const Ray& r, float4 a, float4 b, V3 rcp, bool fast_ok) {
+    if (fast_ok) {
+        float x0 = (a.x - r.o.x) * rcp.x, x1 = (b.x - r.o.x) * rcp.x;
+        float y0 = (a.y - r.o.y) * rcp.y, y1 = (b.y - r.o.y) * rcp.y;
+        float z0 = (a.z - r.o.z) * rcp.z, z1 = (b.z - r.o.z) * rcp.z;
+        float tMin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        float tMax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        float big = fmaxf(fmaxf(fmaxf(fabsf(x0), fabsf(x1)), fmaxf(fabsf(y0), fabsf(y1))), fmaxf(fabsf(z0), fabsf(z1)));
+        float E = 1e-6f * big;                       // > 8 ulp of the largest quotient
+        if (tMin + E < tMax - E) return true;
+        if (tMin - E > tMax + E) return false;
+    }
+    return slab_exact(r, a, b);
 }
 
 // Result of a trace: class 0 plane / 1 cube / 2 sphere, index inside the set, which set it came from.
@@ -315,9 +349,13 @@ DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict_
     if (f.use_bvh) {
         int i = 0;
         const int n = sc.n_nodes;
+        // reciprocal-multiply slab tests are allowed when every direction component is an ordinary number
+        const float ax = fabsf(r.d.x), ay = fabsf(r.d.y), az = fabsf(r.d.z);
+        const bool fast_ok = ax > 1e-18f && ax < 1e18f && ay > 1e-18f && ay < 1e18f && az > 1e-18f && az < 1e18f;
+        const V3 rcp = mk(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
         while (i < n) {
             float4 a = nodes[2 * i], b = nodes[2 * i + 1];
-            if (!slab(r, a, b)) { i = f2i(a.w); continue; }
+            if (!slab(r, a, b, rcp, fast_ok)) { i = f2i(a.w); continue; }
             int leaf = f2i(b.w);
             ++i;
             if (leaf >= 0) {
@@ -445,17 +483,6 @@ DEVI bool generate_primary(const DevFrame& f, int i, Ray& r, uint32_t& path, int
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// level bookkeeping: one thread between two extend launches
-// ---------------------------------------------------------------------------------------------------------
-__global__ void k_level_begin(DevWork w, int level) {
-    int nodes = w.ctr[RT_C_NODE], links = w.ctr[RT_C_LINK];
-    w.ctr[RT_C_NODE_START + level] = nodes;
-    w.ctr[RT_C_LINK_START + level + 1] = links;
-    if (level == 0) w.ctr[RT_C_LINK_START] = 0;
-    else w.ctr[RT_C_RAY_COUNT + level] = links - w.ctr[RT_C_LINK_START + level];
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // extend: trace one ray per lane to the hit the reference would report, append a hit-tree node, and spawn the
 // reflection / refraction rays of the next level (raytracer.cpp:144-164 for primaries, :373-498 for the spawn).
 // ---------------------------------------------------------------------------------------------------------
@@ -465,11 +492,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, DevFrame f, De
     float4* s_nodes = s_mem;
     int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
+    const int count = PRIMARY ? f.pix_count : min(w.ctr[RT_C_LINK_CNT + level], w.link_off[level + 1] - w.link_off[level]);
+    if ((int)(blockIdx.x * blockDim.x) >= count) return;               // whole workgroup idle
     if (f.use_bvh) stage_bvh(sc, s_nodes, s_leaves);
 
-    const int count = PRIMARY ? f.pix_count : w.ctr[RT_C_RAY_COUNT + level];
-    const int link_in = PRIMARY ? 0 : w.ctr[RT_C_LINK_START + level];
-    const int link_out = w.ctr[RT_C_LINK_START + level + 1];
+    const int link_in = PRIMARY ? 0 : w.link_off[level];
+    const int node_base = w.node_off[level], node_cap = w.node_off[level + 1] - w.node_off[level];
+    const int link_out = w.link_off[level + 1], link_cap = w.link_off[level + 2] - w.link_off[level + 1];
     const float4* __restrict__ qa_in = w.q_a[level & 1];
     const float4* __restrict__ qb_in = w.q_b[level & 1];
     float4* __restrict__ qa_out = w.q_a[(level + 1) & 1];
@@ -503,11 +532,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, DevFrame f, De
         {
             int total = __popcll(hm);
             int base = 0;
-            if (__lane_id() == 0 && total) base = atomicAdd(&w.ctr[RT_C_NODE], total);
+            if (__lane_id() == 0 && total) base = atomicAdd(&w.ctr[RT_C_NODE_CNT + level], total);
             base = __shfl(base, 0, 64);
             if (hit) node = base + __popcll(hm & ((1ull << __lane_id()) - 1ull));
         }
-        if (hit && (unsigned)node >= w.cap_nodes) { w.ctr[RT_C_ERR] = 1; hit = false; node = -1; }
+        if (hit && node >= node_cap) { w.stats[RT_S_ERR] = 1; hit = false; }
+        node = hit ? node_base + node : -1;
         if (!PRIMARY && active) w.link[link_in + i] = node;
 
         int n_children = 0, n_reflect = 0; bool refract = false;
@@ -558,11 +588,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, DevFrame f, De
                 n_children = n_reflect + (refract ? 1 : 0);
             }
         }
-        int first_link = wave_alloc(&w.ctr[RT_C_LINK], n_children);
+        const int qslot = wave_alloc(&w.ctr[RT_C_LINK_CNT + level + 1], n_children);
         if (hit) {
-            int qslot = first_link - link_out;
-            if (n_children > 0 && ((unsigned)(qslot + n_children) > w.cap_rays || (unsigned)(first_link + n_children) > w.cap_links)) {
-                w.ctr[RT_C_ERR] = 1; n_children = 0; n_reflect = 0; refract = false;
+            const int first_link = link_out + qslot;
+            if (n_children > 0 && qslot + n_children > link_cap) {
+                w.stats[RT_S_ERR] = 1; n_children = 0; n_reflect = 0; refract = false;
             }
             w.n_c[node] = make_float4(i2f(n_children ? first_link : -1), weight, i2f((int)path),
                                       i2f(n_reflect | (refract ? (1 << 30) : 0)));
@@ -612,26 +642,44 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, DevFrame f, De
     float4* s_nodes = s_mem;
     int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
-    if (f.use_bvh) stage_bvh(sc, s_nodes, s_leaves);
-
-    const int n_nodes = min(w.ctr[RT_C_NODE], (int)w.cap_nodes);
+    __shared__ int s_first[RT_MAX_LEVELS];                              // dense index of each level's first hit
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int lv = 0; lv <= f.max_depth; ++lv) {
+            s_first[lv] = acc;
+            acc += min(w.ctr[RT_C_NODE_CNT + lv], w.node_off[lv + 1] - w.node_off[lv]);
+        }
+        s_first[f.max_depth + 1] = acc;
+    }
+    __syncthreads();
+    const int n_nodes = s_first[f.max_depth + 1];
     const int L = sc.n_lights;
     const int SS = f.soft_shadows ? f.ss_samples : 1;
-    const int per = L * SS;
-    const long long count = (long long)n_nodes * per;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    const long long rounds = (count + stride - 1) / stride;
+    const unsigned per = (unsigned)(L * SS);
+    const unsigned count = (unsigned)n_nodes * per;                      // the host keeps hits x lights x samples below 2^31
+    if (blockIdx.x * blockDim.x >= count) return;
+    if (f.use_bvh) stage_bvh(sc, s_nodes, s_leaves);
+
+    const unsigned stride = gridDim.x * blockDim.x;
+    const unsigned rounds = (count + stride - 1) / stride;
     const bool grouped = (SS <= 64) && ((SS & (SS - 1)) == 0);           // a (hit, light) group sits inside one wavefront
+    const int ss_shift = 31 - __clz(SS);
     int* __restrict__ out = (int*)w.shadow;
     unsigned long long n_rays = 0;
 
-    for (long long it = 0; it < rounds; ++it) {
-        const long long i = it * stride + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned it = 0; it < rounds; ++it) {
+        const unsigned i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         const bool active = i < count;
         bool unblocked = false;
         int node = 0, l = 0, j = 0;
         if (active) {
-            node = (int)(i / per); int rem = (int)(i % per); l = rem / SS; j = rem % SS;
+            unsigned grp;
+            if (grouped) { grp = i >> ss_shift; j = (int)(i & (unsigned)(SS - 1)); } else { grp = i / (unsigned)SS; j = (int)(i % (unsigned)SS); }
+            int dense;
+            if (L == 1) { dense = (int)grp; l = 0; } else { dense = (int)(grp / (unsigned)L); l = (int)(grp % (unsigned)L); }
+            int lv = 0;
+            while (lv < f.max_depth && dense >= s_first[lv + 1]) ++lv;
+            node = w.node_off[lv] + (dense - s_first[lv]);
             float4 a = w.n_a[node], b = w.n_b[node];
             float4 lt = sc.lights[l];
             V3 p = mk(a.x, a.y, a.z);
@@ -678,9 +726,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, DevFrame f, De
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, DevWork w, int level) {
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
-    const int begin = w.ctr[RT_C_NODE_START + level];
-    const int end = min(w.ctr[RT_C_NODE_START + level + 1], (int)w.cap_nodes);
-    const int count = end - begin;
+    const int begin = w.node_off[level];
+    const int count = min(w.ctr[RT_C_NODE_CNT + level], w.node_off[level + 1] - w.node_off[level]);
+    if ((int)(blockIdx.x * blockDim.x) >= count) return;
     const int stride = gridDim.x * blockDim.x;
     const int L = sc.n_lights;
     const int* __restrict__ sh = (const int*)w.shadow;
@@ -824,10 +872,6 @@ __global__ void k_assemble(const unsigned char* __restrict__ tiles, int world, i
 // ---------------------------------------------------------------------------------------------------------
 static size_t bvh_lds_bytes(const DevScene& sc, const DevFrame& f) {
     return f.use_bvh ? (size_t)(2 * sc.n_nodes + 2 * sc.n_leaves) * 16 : 16;
-}
-
-void rt_launch_level_begin(hipStream_t s, const DevWork& w, int level) {
-    hipLaunchKernelGGL(k_level_begin, dim3(1), dim3(1), 0, s, w, level);
 }
 
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {

@@ -76,9 +76,9 @@ struct DevFrame {
 //   n_a = (hit point xyz, hit time)           n_b = (geometric normal xyz, bits gid)
 //   n_c = (bits first_link | -1, refraction weight, bits path id, bits n_reflection_children | has_refraction << 30)
 //   n_uv = (u, v) when texture mapping is on   n_col = resolved colour (r, g, b, 0)
-//   n_pix (level 0 only) = local pixel slot
+//   n_pix (level 0 only) = local pixel slot.  Node index = node_off[level] + order of allocation inside the level.
 // Secondary-ray queue entry: q_a = (origin xyz, dir.x)  q_b = (dir.y, dir.z, bits path id, bits multiplicity)
-// link[k] = node index hit by spawned ray k, or -1
+// link[link_off[level] + k] = node index hit by the k-th ray traced at `level`, or -1; queue slot of that ray = k
 struct DevWork {
     float4* q_a[2]; float4* q_b[2];
     float4* n_a; float4* n_b; float4* n_c; float2* n_uv; float4* n_col; int* n_pix;
@@ -87,26 +87,27 @@ struct DevWork {
     float4* accum;                 // per local pixel slot: running colour sum over samples
     int* ctr;                      // counters, see below
     unsigned long long* stats;     // ray counters, see below
-    unsigned cap_nodes, cap_rays, cap_links;
+    unsigned cap_nodes;            // total node capacity = node_off[max_depth + 1]
+    int node_off[RT_MAX_LEVELS];   // [level] first node of the level's region; [max_depth + 1] = end
+    int link_off[RT_MAX_LEVELS];   // [level] first link of the rays traced at `level` (level >= 1); [max_depth + 1] = end
 };
 
-// ctr[] slots
+// ctr[] slots: per-level allocation counters, zeroed at the start of every batch.  Each recursion level owns a
+// fixed region of the node and link arenas (offsets in DevWork, sized on the host for the worst-case fan-out), so
+// no kernel ever needs another level's running count and there is no bookkeeping between launches.
 enum {
-    RT_C_NODE = 0,                 // nodes allocated in this batch
-    RT_C_LINK = 1,                 // links (= secondary rays) allocated in this batch
-    RT_C_ERR = 2,                  // set when a capacity was exceeded
-    RT_C_NODE_START = 8,           // [level] first node of the level; [max_depth+1] = end
-    RT_C_LINK_START = 8 + RT_MAX_LEVELS,      // [level] first link of the rays traced at `level`
-    RT_C_RAY_COUNT = 8 + 2 * RT_MAX_LEVELS,   // [level] secondary rays to trace at `level` (level >= 1)
-    RT_C_TOTAL = 8 + 3 * RT_MAX_LEVELS
+    RT_C_NODE_CNT = 0,                         // [level] hits recorded at `level`
+    RT_C_LINK_CNT = RT_MAX_LEVELS,             // [level] secondary rays to trace at `level` (level >= 1)
+    RT_C_TOTAL = 2 * RT_MAX_LEVELS
 };
 // stats[] slots
 // *_REF = what the reference would trace: without glossy perturbation it re-traces gr_samples identical reflection
 // rays per hit, and with them their whole subtrees; every ray carries that multiplicity.
-enum { RT_S_PRIMARY = 0, RT_S_SHADOW, RT_S_REFLECT, RT_S_REFRACT, RT_S_NODES, RT_S_SHADOW_REF, RT_S_REFLECT_REF, RT_S_REFRACT_REF, RT_S_TOTAL = 8 };
+enum { RT_S_PRIMARY = 0, RT_S_SHADOW, RT_S_REFLECT, RT_S_REFRACT, RT_S_NODES, RT_S_SHADOW_REF, RT_S_REFLECT_REF, RT_S_REFRACT_REF,
+       RT_S_ERR = 8,               // non-zero when a capacity was exceeded during the frame
+       RT_S_TOTAL = 16 };
 
 // kernel launchers (rt_kernels.hip)
-void rt_launch_level_begin(hipStream_t s, const DevWork& w, int level);
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);
 void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid);
 void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);

@@ -30,6 +30,7 @@ def reference_scene(w: int = 1920, h: int = 1080) -> str:
 
 SCENES = {
     "ref": lambda: reference_scene(240, 135),
+    "ref120": lambda: reference_scene(120, 68),
     "glass": lambda: sg.glass_scene((200, 112)),
     "glass_tex": lambda: sg.glass_scene((200, 112), True),
     "cluster16": lambda: sg.cluster_scene(16, 7, (200, 112)),
@@ -67,8 +68,9 @@ STOCHASTIC = [
     ("ref", ["-dof", "-dofs", "256"]),
     ("ref", ["-m", "-mbs", "256"]),
     ("ref", ["-r", "-gr", "-grs", "256"]),
-    ("glass_tex", ["-t", "-aa", "-aas", "16", "-ss", "-sss", "16", "-r", "-grs", "1"]),
-    ("ref", ["-aa", "-aas", "4", "-dof", "-dofs", "8", "-m", "-mbs", "8", "-ss", "-sss", "8"]),
+    ("glass_tex", ["-t", "-aa", "-aas", "256", "-r", "-grs", "1"]),
+    # the flag set of the 4K multi-sample configuration (4096 samples per pixel) on a small film
+    ("ref120", ["-aa", "-aas", "16", "-gr", "-grs", "16", "-dof", "-dofs", "16", "-m", "-mbs", "16"]),
 ]
 
 

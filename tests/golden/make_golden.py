@@ -27,6 +27,15 @@ def run(job):
 
 
 def main():
+    if len(sys.argv) > 1:            # regenerate only the named cases, keep the rest
+        for fname, catalogue in (("deterministic.npz", cases.DETERMINISTIC), ("stochastic.npz", cases.STOCHASTIC)):
+            have = dict(np.load(HERE / fname))
+            want = {cases.case_id(s, f) for s, f in catalogue}
+            for job in catalogue:
+                if cases.case_id(*job) in sys.argv[1:]:
+                    k, v, secs = run(job); have[k] = v; print(f"{k:60s} {secs:8.2f} s")
+            np.savez_compressed(HERE / fname, **{k: v for k, v in have.items() if k in want})
+        return
     with ProcessPoolExecutor(max_workers=6) as ex:
         det = list(ex.map(run, cases.DETERMINISTIC))
         sto = list(ex.map(run, cases.STOCHASTIC))

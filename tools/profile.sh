@@ -1,0 +1,16 @@
+#!/bin/bash
+# Kernel-trace statistics and HBM/SQ counters of `bench.py` (each counter group in a pass of its own).
+# usage: tools/profile.sh <tag> [bench args...]      outputs under gpurun_out/prof_<tag>/
+set -u
+TAG=$1; shift
+OUT=gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline $*"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $ARGS > "$OUT/pmc_fetch.log" 2>&1 || { echo "fetch pass failed"; tail -5 "$OUT/pmc_fetch.log"; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $ARGS > "$OUT/pmc_write.log" 2>&1 || { echo "write pass failed"; tail -5 "$OUT/pmc_write.log"; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $ARGS > "$OUT/pmc_sq.log" 2>&1 || { echo "sq pass failed"; tail -5 "$OUT/pmc_sq.log"; exit 1; }
+python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt"
