@@ -105,9 +105,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a one-GPU machine: every rank uses GPU 0 (use with --backend gloo)")
     args = ap.parse_args()
 
-    rank, world, local = rdist.init_process_group()
+    if args.single_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = rdist.init_process_group(args.backend)
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -122,7 +127,7 @@ def main():
     W, H = wl["res"]
     # scene text and flags come from rank 0 (one broadcast per frame set)
     payload = json.dumps({"text": cases.reference_scene(W, H), "flags": wl["flags"]}).encode() if rank == 0 else None
-    payload = json.loads(rdist.broadcast_bytes(payload, 0, dev if world > 1 else None).decode())
+    payload = json.loads(rdist.broadcast_bytes(payload, 0, dev if (world > 1 and args.backend != "gloo") else None).decode())
     cfg, _ = api.parse_args(payload["flags"])
     ls = api.LoadedScene(payload["text"], cfg, str(cases.TEXTURES))
     r = api.Renderer(local, workspace_bytes=16 << 30)
@@ -138,13 +143,23 @@ def main():
     block = torch.empty(r.out_bytes(), dtype=torch.uint8, device=dev)
     image = torch.empty(H * W * 3, dtype=torch.uint8, device=dev) if rank == 0 else None
 
+    staged = args.backend == "gloo"      # rehearsal path: gloo moves host tensors
+
     def step():
         r.render_device(cfg, block.data_ptr())
         if world > 1:
-            gathered = rdist.gather_blocks(block, 0)
+            if staged:
+                g = rdist.gather_blocks(block.cpu(), 0)
+                gathered = g.to(dev) if rank == 0 else None
+            else:
+                gathered = rdist.gather_blocks(block, 0)
             if rank == 0:
                 r.assemble(gathered.data_ptr(), world, image.data_ptr())
+                keep.append(gathered)            # the assemble kernel is only enqueued: keep its input alive
+                del keep[:-2]
         return None
+
+    keep = []
 
     # Ray counts (identical every frame: the generator is counter based) and per-kernel device times.  The profiled
     # frame is enqueued behind four ordinary ones so that the GPU, not the host, paces it.
@@ -155,6 +170,7 @@ def main():
                                st.shadow_rays_ref + st.reflection_rays_ref + st.refraction_rays_ref, st.nodes_shaded],
                               dtype=torch.float64, device=dev)
     if world > 1:
+        rays_local = rays_local.cpu() if staged else rays_local
         dist.all_reduce(rays_local)
     tot = [int(x) for x in rays_local.tolist()]
     rays_total = tot[0] + tot[1] + tot[2] + tot[3]
@@ -175,7 +191,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staged else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

@@ -181,6 +181,12 @@ void rt_destroy(rt_ctx* ctx);
 /* Work is enqueued on `hip_stream` (a hipStream_t; NULL = the context's own stream). */
 int rt_set_stream(rt_ctx* ctx, void* hip_stream);
 
+/* Implementation options (no counterpart in the reference; none of them changes a rendered value). Set before
+ * rt_upload_scene.  "second_level_min_group" = N: groups of more than N primitives (a leaf of the reference's
+ * depth-8 tree, or the whole scene for -u) are searched through a second-level hierarchy instead of one by
+ * one; default 8, a huge value turns the hierarchy off. */
+int rt_set_option(rt_ctx* ctx, const char* name, int64_t value);
+
 /* Copies the scene to the device (replaces raytracer.cpp:55-59 as the producer of the render loop's inputs). */
 int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene);
 

@@ -43,6 +43,8 @@ def lib():
         L.orc_camera_ray.argtypes = [C.c_char_p, C.c_float, C.c_float, C.POINTER(C.c_float)]
         L.orc_bvh_dump.argtypes = [C.c_char_p, C.POINTER(OrcConfig), C.POINTER(C.c_float), C.c_int]
         L.orc_last_error.restype = C.c_char_p
+        L.orc_set_window.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_set_window.restype = None
         _lib = L
     return _lib
 
@@ -55,14 +57,19 @@ def parse_args(flags: list[str]) -> OrcConfig:
     return cfg
 
 
-def render(scene_text: str, flags: list[str], textures_dir: str | None = None, rand_seed: int = 1):
-    """Returns (image int32 [H,W,3], OrcStats). rand_seed=1 is the state of a process that never called srand."""
+def render(scene_text: str, flags: list[str], textures_dir: str | None = None, rand_seed: int = 1, window=None):
+    """Returns (image int32 [H,W,3], OrcStats). rand_seed=1 is the state of a process that never called srand.
+    window = (x0, y0, x1, y1): render only those pixels (exact for deterministic flag sets), the rest stays 0."""
     from ref_runner import get_resolution  # same directory
     w, h = get_resolution(scene_text)
     cfg = parse_args(flags)
     out = np.zeros(w * h * 3, dtype=np.int32)
     W, H = C.c_int(), C.c_int()
     st = OrcStats()
+    if window is not None:
+        lib().orc_set_window(*[int(v) for v in window])
+    else:
+        lib().orc_set_window(0, 0, 1 << 30, 1 << 30)
     rc = lib().orc_render(scene_text.encode(), textures_dir.encode() if textures_dir else None, C.byref(cfg),
                           rand_seed, out.ctypes.data_as(C.POINTER(C.c_int)), out.size, C.byref(W), C.byref(H),
                           C.byref(st))

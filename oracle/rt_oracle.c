@@ -117,6 +117,10 @@ typedef struct { float p[3], t, n[3]; const Mat* m; float time, u, v; int hasTex
 typedef struct { float o[3], d[3], time; Hit last; int nh; } Ray;
 
 static orc_stats* g_stats;
+/* Optional pixel window (x0, y0, x1, y1; x1/y1 exclusive): pixels outside it are skipped and left 0.  For
+ * deterministic flag sets a pixel's value does not depend on the others, so a window is an exact crop. */
+static int g_win[4] = { 0, 0, 1 << 30, 1 << 30 };
+void orc_set_window(int x0, int y0, int x1, int y1) { g_win[0] = x0; g_win[1] = y0; g_win[2] = x1; g_win[3] = y1; }
 
 /* ------------------------------------------------------------------------------------------------
  * Vector helpers (raytracer.cpp:577-631, 671-673)
@@ -1142,6 +1146,7 @@ int orc_render(const char* scene_text, const char* textures_dir, const orc_confi
     /* the loop bounds compare an int against the float resolution (raytracer.cpp:111-112) */
     for (int y = 0; y < cam->res_y; ++y) {
         for (int x = 0; x < cam->res_x; ++x) {
+            if (x < g_win[0] || x >= g_win[2] || y < g_win[1] || y >= g_win[3]) continue;
             float pc[3] = { 0.0f, 0.0f, 0.0f };
             float u, v;
             for (int s = 0; s < AA; ++s) {

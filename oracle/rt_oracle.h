@@ -53,6 +53,10 @@ int orc_parse_args(int argc, const char* const* argv, orc_config* c, char* out_n
 int orc_render(const char* scene_text, const char* textures_dir, const orc_config* c, int rand_seed,
                int* rgb_out, long long rgb_cap, int* width, int* height, orc_stats* stats);
 
+/* Restrict the following orc_render calls to the pixel window [x0,x1) x [y0,y1) (others stay 0). An exact crop for
+ * deterministic flag sets only. orc_set_window(0, 0, 1 << 30, 1 << 30) restores the full frame. */
+void orc_set_window(int x0, int y0, int x1, int y1);
+
 /* Known-answer helpers (same parsing + build as orc_render). */
 /* Camera::convertPixelToRay, camera.cpp:109-199, with aperture 0 (no lens sample). out6 = origin, direction. */
 int orc_camera_ray(const char* scene_text, float x, float y, float* out6);

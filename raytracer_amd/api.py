@@ -108,7 +108,7 @@ class HostBvh(C.Structure):
 
 
 # every symbol the two headers declare
-API_SYMBOLS = ["rt_default_config", "rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_upload_bvh",
+API_SYMBOLS = ["rt_default_config", "rt_create", "rt_destroy", "rt_set_stream", "rt_set_option", "rt_upload_scene", "rt_upload_bvh",
                "rt_set_shard", "rt_local_tiles", "rt_max_tiles_per_rank", "rt_render", "rt_render_device",
                "rt_assemble_tiles", "rt_synchronize", "rt_last_error"]
 HOST_SYMBOLS = ["rt_host_parse_args", "rt_host_parse_scene", "rt_host_load_scene", "rt_host_free_scene",
@@ -130,6 +130,7 @@ def lib():
     L.rt_create.argtypes = [C.c_int, C.c_uint64]; L.rt_create.restype = C.c_void_p
     L.rt_destroy.argtypes = [C.c_void_p]; L.rt_destroy.restype = None
     L.rt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.rt_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.rt_upload_scene.argtypes = [C.c_void_p, C.POINTER(Scene)]
     L.rt_upload_bvh.argtypes = [C.c_void_p, C.POINTER(BvhNode), C.c_int32, C.POINTER(C.c_int32), C.c_int32]
     L.rt_set_shard.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
@@ -226,6 +227,76 @@ class LoadedScene:
             pass
 
 
+class ArrayScene(LoadedScene):
+    """The population of scenegen.random_prims turned straight into the C-ABI arrays (no scene text): what a
+    caller with millions of primitives does instead of writing and re-parsing hundreds of MB of JSON.
+    Same values as parsing scenegen.random_scene's text (float32 of the same float64 numbers)."""
+
+    def __init__(self, table: np.ndarray, res=(1920, 1080), with_ground=True, moving=False):
+        from . import scenegen as sg
+        self._hs = None; self._bvh = None
+        t = np.asarray(table, dtype=np.float64)
+        sph, cub = t[t[:, 12] == 0], t[t[:, 12] == 1]
+
+        def mats(rows, arr):
+            for k in range(3):
+                arr["mat"]["diffuse"][:, k] = rows[:, 4 + k]
+                arr["mat"]["specular"][:, k] = 0.3
+            arr["mat"]["shininess"] = 64.0; arr["mat"]["transparency"] = rows[:, 7]; arr["mat"]["ior"] = 1.5
+            arr["mat"]["tex_id"] = -1
+
+        mat_dt = np.dtype([("diffuse", "<f4", 3), ("specular", "<f4", 3), ("shininess", "<f4"), ("transparency", "<f4"),
+                           ("ior", "<f4"), ("tex_id", "<i4")])
+        sdt = np.dtype([("start", "<f4", 3), ("end", "<f4", 3), ("radius", "<f4"), ("mat", mat_dt)])
+        cdt = np.dtype([("start", "<f4", 3), ("end", "<f4", 3), ("rotation", "<f4", 3), ("scale", "<f4"), ("mat", mat_dt)])
+        assert sdt.itemsize == C.sizeof(Sphere) and cdt.itemsize == C.sizeof(Cube)
+        self._s = np.zeros(len(sph), dtype=sdt); self._c = np.zeros(len(cub), dtype=cdt)
+        for arr, rows in ((self._s, sph), (self._c, cub)):
+            arr["start"] = rows[:, 0:3]; arr["end"] = rows[:, 0:3]
+            if moving:
+                arr["end"][:, 2] = (rows[:, 2] + rows[:, 8]).astype(np.float32)
+            mats(rows, arr)
+        self._s["radius"] = sph[:, 3]; self._c["scale"] = cub[:, 3]; self._c["rotation"] = cub[:, 9:12]
+        self._lights = (Light * 1)(); self._lights[0].location[:] = sg.REF_LIGHT; self._lights[0].rad_intensity = 1000.0
+        n_planes = 1 if with_ground else 0
+        self._planes = (Plane * max(1, n_planes))()
+        self._verts = np.array([[-25, -25, 0], [25, -25, 0], [-25, 25, 0], [25, 25, 0]], dtype=np.float32)
+        if with_ground:
+            p = self._planes[0]; p.n_verts = 4; p.first_vert = 0; p.normal[:] = (0.0, 0.0, 1.0)
+            p.mat.diffuse[:] = sg.GROUND_DIFFUSE; p.mat.specular[:] = (0.3, 0.3, 0.3)
+            p.mat.shininess = 64.0; p.mat.transparency = 0.0; p.mat.ior = 1.5; p.mat.tex_id = -1
+        sc = Scene()
+        cam = sc.camera
+        cam.location[:] = (0.0, -8.0, 1.5); cam.gaze[:] = (0.0, 1.0, 0.0); cam.aperture = 0.0
+        cam.focal_length = np.float32(50.0) / np.float32(1000.0); cam.focal_distance = 0.0
+        cam.sensor_width = np.float32(36.0) / np.float32(1000.0); cam.sensor_height = np.float32(24.0) / np.float32(1000.0)
+        cam.res_x, cam.res_y = float(res[0]), float(res[1])
+        sc.n_lights = 1; sc.lights = self._lights
+        sc.n_spheres = len(self._s); sc.spheres = self._s.ctypes.data_as(C.POINTER(Sphere))
+        sc.n_cubes = len(self._c); sc.cubes = self._c.ctypes.data_as(C.POINTER(Cube))
+        sc.n_planes = n_planes; sc.planes = self._planes
+        sc.n_plane_verts = 4 if with_ground else 0; sc.plane_verts = self._verts.ctypes.data_as(C.POINTER(C.c_float))
+        sc.n_textures = 0; sc.textures = None
+        self._scene = sc
+
+    @property
+    def scene(self) -> Scene:
+        return self._scene
+
+    def bvh(self, max_depth: int = 8) -> HostBvh:
+        if self._bvh is None:
+            b = HostBvh()
+            rc = lib().rt_host_build_bvh(C.byref(self._scene), max_depth, C.byref(b))
+            if rc != RT_OK:
+                raise RtError(rc, "rt_host_build_bvh failed")
+            self._bvh = b
+        return self._bvh
+
+    def close(self):
+        if self._bvh is not None:
+            lib().rt_host_free_bvh(C.byref(self._bvh)); self._bvh = None
+
+
 def camera_ray(cam: Camera, x: float, y: float) -> np.ndarray:
     out = (C.c_float * 6)()
     lib().rt_host_camera_ray(C.byref(cam), x, y, out)
@@ -268,6 +339,9 @@ class Renderer:
 
     def set_stream(self, stream_handle: int | None):
         self._check(lib().rt_set_stream(self._ctx, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def set_option(self, name: str, value: int):
+        self._check(lib().rt_set_option(self._ctx, name.encode(), value))
 
     def upload(self, ls: LoadedScene, with_bvh: bool = True):
         self._check(lib().rt_upload_scene(self._ctx, C.byref(ls.scene)))

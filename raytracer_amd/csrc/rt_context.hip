@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -70,6 +71,100 @@ float len_ref(const float v[3]) {
     return (float)std::sqrt((double)v[0] * (double)v[0] + (double)v[1] * (double)v[1] + (double)v[2] * (double)v[2]);
 }
 
+// ---- true bounds of the primitives (NOT the reference's shape boxes, which under-cover moving scaled cubes):
+// everything a primitive can occupy for ray times in [0,1], slightly enlarged for the rounding of this very
+// computation.  They only steer the second-level hierarchy, never a reported result.
+struct Box3 {
+    float mn[3], mx[3];
+    void clear() { for (int i = 0; i < 3; ++i) { mn[i] = INFINITY; mx[i] = -INFINITY; } }
+    void add(const float p[3]) { for (int i = 0; i < 3; ++i) { mn[i] = std::min(mn[i], p[i]); mx[i] = std::max(mx[i], p[i]); } }
+    void add(const Box3& o) { for (int i = 0; i < 3; ++i) { mn[i] = std::min(mn[i], o.mn[i]); mx[i] = std::max(mx[i], o.mx[i]); } }
+    void grow() {
+        for (int i = 0; i < 3; ++i) {
+            float e = 1e-5f * std::max(std::max(std::fabs(mn[i]), std::fabs(mx[i])), mx[i] - mn[i]) + 1e-6f;
+            mn[i] -= e; mx[i] += e;
+        }
+    }
+};
+
+Box3 true_box(const rt_sphere& s) {
+    Box3 b; b.clear();
+    for (int k = 0; k < 2; ++k) {
+        const float* c = k ? s.end : s.start; float r = std::fabs(s.radius);
+        float lo[3] = { c[0] - r, c[1] - r, c[2] - r }, hi[3] = { c[0] + r, c[1] + r, c[2] + r };
+        b.add(lo); b.add(hi);
+    }
+    b.grow(); return b;
+}
+
+Box3 true_box(const rt_cube& c) {
+    Box3 b; b.clear();
+    const float cx = std::cos(c.rotation[0]), sx = std::sin(c.rotation[0]), cy = std::cos(c.rotation[1]), sy = std::sin(c.rotation[1]);
+    const float cz = std::cos(c.rotation[2]), sz = std::sin(c.rotation[2]);
+    for (int m = 0; m < 8; ++m) {
+        float x = (m & 1) ? 1.0f : -1.0f, y = (m & 2) ? 1.0f : -1.0f, z = (m & 4) ? 1.0f : -1.0f;
+        float y1 = y * cx - z * sx, z1 = y * sx + z * cx;
+        float x2 = x * cy + z1 * sy, z2 = -x * sy + z1 * cy;
+        float r[3] = { (x2 * cz - y1 * sz) * c.scale, (x2 * sz + y1 * cz) * c.scale, z2 * c.scale };
+        for (int k = 0; k < 2; ++k) {
+            const float* o = k ? c.end : c.start;
+            float p[3] = { r[0] + o[0], r[1] + o[1], r[2] + o[2] };
+            b.add(p);
+        }
+    }
+    b.grow(); return b;
+}
+
+Box3 true_box(const rt_plane& p, const float* verts) {
+    Box3 b; b.clear();
+    for (int k = 0; k < p.n_verts; ++k) b.add(verts + (size_t)(p.first_vert + k) * 3);
+    b.grow(); return b;
+}
+
+// ---- second-level hierarchy builder: median split on the widest centroid axis, runs of <= RT_SUB_LEAF entries
+struct SubItem { unsigned entry; Box3 box; float cen[3]; };
+struct SubRef { int ref, cnt; Box3 box; };
+
+struct SubBuilder {
+    std::vector<float4>& nodes;      // 4 words per interior node
+    std::vector<int>& entries;
+    int max_depth = 0;
+
+    SubRef build(std::vector<SubItem>& it, size_t lo, size_t hi, int depth) {
+        max_depth = std::max(max_depth, depth);
+        SubRef out; out.box.clear();
+        if (hi - lo <= RT_SUB_LEAF) {
+            std::sort(it.begin() + (long)lo, it.begin() + (long)hi, [](const SubItem& a, const SubItem& b) { return a.entry < b.entry; });
+            out.ref = ~(int)entries.size(); out.cnt = (int)(hi - lo);
+            for (size_t i = lo; i < hi; ++i) { entries.push_back((int)it[i].entry); out.box.add(it[i].box); }
+            return out;
+        }
+        float cmn[3] = { INFINITY, INFINITY, INFINITY }, cmx[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (size_t i = lo; i < hi; ++i) for (int k = 0; k < 3; ++k) { cmn[k] = std::min(cmn[k], it[i].cen[k]); cmx[k] = std::max(cmx[k], it[i].cen[k]); }
+        int axis = 0;
+        if (cmx[1] - cmn[1] > cmx[axis] - cmn[axis]) axis = 1;
+        if (cmx[2] - cmn[2] > cmx[axis] - cmn[axis]) axis = 2;
+        size_t mid = lo + (hi - lo) / 2;
+        std::nth_element(it.begin() + (long)lo, it.begin() + (long)mid, it.begin() + (long)hi,
+                         [axis](const SubItem& a, const SubItem& b) { return a.cen[axis] < b.cen[axis] || (a.cen[axis] == b.cen[axis] && a.entry < b.entry); });
+        size_t me = nodes.size() / 4;
+        nodes.resize(nodes.size() + 4);
+        SubRef L = build(it, lo, mid, depth + 1), R = build(it, mid, hi, depth + 1);
+        nodes[me * 4 + 0] = f4(L.box.mn[0], L.box.mn[1], L.box.mn[2], as_f(L.ref));
+        nodes[me * 4 + 1] = f4(L.box.mx[0], L.box.mx[1], L.box.mx[2], as_f(L.cnt));
+        nodes[me * 4 + 2] = f4(R.box.mn[0], R.box.mn[1], R.box.mn[2], as_f(R.ref));
+        nodes[me * 4 + 3] = f4(R.box.mx[0], R.box.mx[1], R.box.mx[2], as_f(R.cnt));
+        out.ref = (int)me; out.cnt = 0; out.box = L.box; out.box.add(R.box);
+        return out;
+    }
+};
+
+SubItem make_item(int cls, int idx, const Box3& b) {
+    SubItem it; it.entry = ((unsigned)cls << 30) | (unsigned)idx; it.box = b;
+    for (int k = 0; k < 3; ++k) it.cen[k] = 0.5f * (b.mn[k] + b.mx[k]);
+    return it;
+}
+
 } // namespace
 
 struct rt_ctx {
@@ -88,6 +183,12 @@ struct rt_ctx {
     std::vector<float4> h_file_planes, h_file_cubes, h_file_spheres;
     int n_lights = 0;
     bool any_reflective = false, any_transparent = false;
+    // true bounds per primitive (file order) and the second-level hierarchy of the file-order set
+    std::vector<Box3> tb_planes, tb_cubes, tb_spheres;
+    std::vector<float4> h_sub_nodes_file; std::vector<int> h_sub_entries_file;
+    int file_sub_root = -1;
+    int sub_min_group = RT_SUB_MIN_GROUP;    // groups above this size get a second-level hierarchy (rt_set_option)
+    DevBuf<float4> d_sub_nodes; DevBuf<int> d_sub_entries;
 
     // device scene
     DevBuf<float4> d_nodes, d_mats, d_plane_uv, d_texels, d_lights, d_verts;
@@ -164,6 +265,7 @@ void rt_destroy(rt_ctx* c) {
                               &c->d_file_cubes, &c->d_file_spheres, &c->d_leaf_planes, &c->d_leaf_cubes, &c->d_leaf_spheres,
                               &c->q_a[0], &c->q_a[1], &c->q_b[0], &c->q_b[1], &c->n_a, &c->n_b, &c->n_c, &c->n_col, &c->accum };
     for (auto* b : f4s) b->release();
+    c->d_sub_nodes.release(); c->d_sub_entries.release();
     c->d_leaves.release(); c->d_tex_desc.release(); c->d_local_tiles.release(); c->n_uv.release(); c->n_pix.release();
     c->link.release(); c->ctr.release(); c->shadow.release(); c->stats.release(); c->out_tmp.release();
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -175,6 +277,16 @@ int rt_set_stream(rt_ctx* c, void* hip_stream) {
     if (!c) return RT_ERR_ARG;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return RT_OK;
+}
+
+int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
+    if (!c || !name) return RT_ERR_ARG;
+    if (std::strcmp(name, "second_level_min_group") == 0) {
+        if (value < RT_SUB_LEAF) return c->fail(RT_ERR_ARG, "second_level_min_group must be >= %d", RT_SUB_LEAF);
+        c->sub_min_group = value > 0x7fffffff ? 0x7fffffff : (int)value;
+        return RT_OK;
+    }
+    return c->fail(RT_ERR_ARG, "unknown option %s", name);
 }
 
 const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
@@ -290,7 +402,56 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
             texels[base + k] = f4(tx.rgb[3 * k] / 255.0f, tx.rgb[3 * k + 1] / 255.0f, tx.rgb[3 * k + 2] / 255.0f, 0.0f);
     }
 
+    // true bounds, the sphere around all of them, and the second-level hierarchy over the whole file-order set
+    c->tb_planes.resize((size_t)np); c->tb_cubes.resize((size_t)nc); c->tb_spheres.resize((size_t)ns);
+    Box3 all; all.clear();
+    for (int i = 0; i < np; ++i) { c->tb_planes[i] = true_box(sc->planes[i], sc->plane_verts); all.add(c->tb_planes[i]); }
+    for (int i = 0; i < nc; ++i) { c->tb_cubes[i] = true_box(sc->cubes[i]); all.add(c->tb_cubes[i]); }
+    for (int i = 0; i < ns; ++i) { c->tb_spheres[i] = true_box(sc->spheres[i]); all.add(c->tb_spheres[i]); }
+    if (ns > 0) {
+        // The sphere test forms |l|^2 - tca^2 in float (sphere.cpp:131-139): a difference of two numbers of the size
+        // of the squared distance to the centre, so far-away spheres are reported hit by rays that pass a little
+        // outside them.  With e = 6e-7 * Dmax^2 bounding that rounding error (Dmax = largest distance between a ray
+        // origin - the camera or a point of the scene - and a centre), a reported hit lies within sqrt(r^2 + e) of
+        // the centre; the boxes that steer the second-level hierarchy are enlarged accordingly.
+        Box3 reach = all; reach.add(sc->camera.location);
+        double diag2 = 0.0;
+        for (int k = 0; k < 3; ++k) { double d = (double)reach.mx[k] - (double)reach.mn[k] + 0.05; diag2 += d * d; }
+        const double e = 6e-7 * diag2;
+        all.clear();
+        for (int i = 0; i < np; ++i) all.add(c->tb_planes[i]);
+        for (int i = 0; i < nc; ++i) all.add(c->tb_cubes[i]);
+        for (int i = 0; i < ns; ++i) {
+            const double r = std::fabs((double)sc->spheres[i].radius);
+            const float extra = (float)(std::sqrt(r * r + e) - r) * 1.01f;
+            Box3& b = c->tb_spheres[i];
+            if (extra < INFINITY) for (int k = 0; k < 3; ++k) { b.mn[k] -= extra; b.mx[k] += extra; }
+            all.add(b);
+        }
+    }
+    float centre[3] = { 0.0f, 0.0f, 0.0f }, radius = 1.0f;
+    if (np + nc + ns > 0) {
+        float half[3];
+        for (int k = 0; k < 3; ++k) { centre[k] = 0.5f * (all.mn[k] + all.mx[k]); half[k] = 0.5f * (all.mx[k] - all.mn[k]); }
+        radius = std::sqrt(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]);
+        if (!(radius < 1e30f)) { radius = 1e30f; for (int k = 0; k < 3; ++k) if (!(std::fabs(centre[k]) < 1e30f)) centre[k] = 0.0f; }
+    }
+    c->h_sub_nodes_file.clear(); c->h_sub_entries_file.clear(); c->file_sub_root = -1;
+    if (np + nc + ns > c->sub_min_group) {
+        if (np >= (1 << 30) || nc >= (1 << 30) || ns >= (1 << 30)) return c->fail(RT_ERR_ARG, "too many primitives of one class");
+        std::vector<SubItem> items; items.reserve((size_t)(np + nc + ns));
+        for (int i = 0; i < np; ++i) items.push_back(make_item(0, i, c->tb_planes[i]));
+        for (int i = 0; i < nc; ++i) items.push_back(make_item(1, i, c->tb_cubes[i]));
+        for (int i = 0; i < ns; ++i) items.push_back(make_item(2, i, c->tb_spheres[i]));
+        SubBuilder sb{ c->h_sub_nodes_file, c->h_sub_entries_file };
+        SubRef root = sb.build(items, 0, items.size(), 0);
+        if (sb.max_depth + 2 > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_STACK - 2);
+        c->file_sub_root = root.ref;
+    }
+
     hipStream_t s = c->stream;
+    RT_HIP(c, c->d_sub_nodes.upload(c->h_sub_nodes_file, s));
+    RT_HIP(c, c->d_sub_entries.upload(c->h_sub_entries_file, s));
     RT_HIP(c, c->d_mats.upload(mats, s));
     RT_HIP(c, c->d_plane_uv.upload(plane_uv, s));
     RT_HIP(c, c->d_verts.upload(c->h_verts_sorted, s));
@@ -309,6 +470,10 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
     d.leafset = d.fileset;
     d.mats = c->d_mats.p; d.plane_uv = c->d_plane_uv.p; d.tex_desc = c->d_tex_desc.p; d.texels = c->d_texels.p;
     d.lights = c->d_lights.p; d.n_lights = sc->n_lights;
+    d.sub_nodes = c->h_sub_nodes_file.empty() ? nullptr : c->d_sub_nodes.p;
+    d.sub_entries = c->d_sub_entries.p; d.file_sub_root = c->file_sub_root;
+    for (int k = 0; k < 3; ++k) d.center[k] = centre[k];
+    d.radius = radius;
     c->have_scene = true;
     c->rebuild_tiles();
     RT_HIP(c, c->d_local_tiles.upload(c->local_tiles, s));
@@ -322,6 +487,7 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->have_bvh = false;
+    c->scene.n_nodes = 0; c->scene.n_leaves = 0;
     if (!nodes || n_nodes <= 0) return RT_OK;
     if (n_prim_ids < 0 || (n_prim_ids && !prim_ids)) return c->fail(RT_ERR_ARG, "bad prim_ids");
     const int np = (int)c->planes.size(), nc = (int)c->cubes.size(), ns = (int)c->spheres.size();
@@ -334,6 +500,9 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
     struct Out { float mn[3], mx[3]; int skip, leaf; };
     std::vector<Out> out; std::vector<int4> leaves;
     std::vector<float4> lp, lc, ls;
+    std::vector<float4> sub_nodes = c->h_sub_nodes_file;      // the file-order hierarchy keeps its node indices
+    std::vector<int> sub_entries = c->h_sub_entries_file;
+    std::vector<SubItem> items;
     std::vector<char> seen((size_t)n_nodes, 0);
     std::string problem;
     // iterative pre-order, right child first
@@ -364,7 +533,9 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
             if (n.n_planes < 0 || n.n_cubes < 0 || n.n_spheres < 0 || n.first_prim < 0 || n.first_prim + cnt > n_prim_ids) { problem = "leaf range out of bounds"; break; }
             o.leaf = (int)(leaves.size() / 2);
             leaves.push_back(make_int4((int)(lp.size() / 3), n.n_planes, (int)(lc.size() / 6), n.n_cubes));
-            leaves.push_back(make_int4((int)(ls.size() / 2), n.n_spheres, 0, 0));
+            leaves.push_back(make_int4((int)(ls.size() / 2), n.n_spheres, -1, 0));
+            const size_t leaf_rec = leaves.size() - 1;
+            const int lp0 = (int)(lp.size() / 3), lc0 = (int)(lc.size() / 6), ls0 = (int)(ls.size() / 2);
             const int32_t* ids = prim_ids + n.first_prim;
             for (int k = 0; k < n.n_planes; ++k) {
                 int id = ids[k]; if (id < 0 || id >= np) { problem = "plane id out of range"; break; }
@@ -386,6 +557,16 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
                 for (int q = 0; q < 2; ++q) ls.push_back(c->h_file_spheres[(size_t)id * 2 + q]);
             }
             if (!problem.empty()) break;
+            if (cnt > c->sub_min_group) {           // second-level hierarchy over this leaf's primitives (leaf-order indices)
+                items.clear(); items.reserve((size_t)cnt);
+                for (int k = 0; k < n.n_planes; ++k) items.push_back(make_item(0, lp0 + k, c->tb_planes[(size_t)ids[k]]));
+                for (int k = 0; k < n.n_cubes; ++k) items.push_back(make_item(1, lc0 + k, c->tb_cubes[(size_t)ids[n.n_planes + k]]));
+                for (int k = 0; k < n.n_spheres; ++k) items.push_back(make_item(2, ls0 + k, c->tb_spheres[(size_t)ids[n.n_planes + n.n_cubes + k]]));
+                SubBuilder sb{ sub_nodes, sub_entries };
+                SubRef root = sb.build(items, 0, items.size(), 0);
+                if (sb.max_depth + 2 > RT_SUB_STACK) { problem = "second-level hierarchy too deep"; break; }
+                leaves[leaf_rec].z = root.ref;
+            }
             out.push_back(o);
             out[(size_t)my].skip = my + 1;
         } else {
@@ -411,8 +592,11 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
     RT_HIP(c, c->d_leaf_planes.upload(lp, s));
     RT_HIP(c, c->d_leaf_cubes.upload(lc, s));
     RT_HIP(c, c->d_leaf_spheres.upload(ls, s));
+    RT_HIP(c, c->d_sub_nodes.upload(sub_nodes, s));
+    RT_HIP(c, c->d_sub_entries.upload(sub_entries, s));
     RT_HIP(c, hipStreamSynchronize(s));
     DevScene& d = c->scene;
+    d.sub_nodes = sub_nodes.empty() ? nullptr : c->d_sub_nodes.p; d.sub_entries = c->d_sub_entries.p;
     d.nodes = c->d_nodes.p; d.n_nodes = (int)out.size();
     d.leaves = c->d_leaves.p; d.n_leaves = (int)(leaves.size() / 2);
     d.leafset.planes = c->d_leaf_planes.p; d.leafset.verts = c->d_verts.p; d.leafset.cubes = c->d_leaf_cubes.p;

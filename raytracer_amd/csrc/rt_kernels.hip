@@ -337,6 +337,106 @@ DEVI bool test_prims(const DevPrimSet& S, const Ray& r, bool mb, int p0, int pn,
     return hit;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Second-level hierarchy.  The reference's tree stops at depth 8, so a leaf of a large scene holds thousands of
+// primitives, and its leaf rule (and the brute-force rule) is "closest reported distance, the earlier primitive
+// wins an exact tie".  That result does not depend on the order of testing, so groups of more than a few
+// primitives get a conventional binary BVH over their TRUE bounds, walked front to back with an LDS stack:
+//   * a candidate replaces the best one if it is nearer, or exactly as near and earlier in the reference's
+//     testing order (planes, cubes, spheres; file order inside a class) - the packed entry is that order;
+//   * a subtree is skipped only when the ray provably cannot report a hit in it that would win: its box,
+//     enlarged by `pad`, is missed or entered beyond the best distance, all with slack for rounding.  `pad`
+//     covers what a primitive test may report outside the primitive's true bounds (a cube test treats a
+//     direction component below 1e-5 as zero, which moves the reported point by up to 1e-5 x distance).
+// An interior node holds both children's boxes: (minL, refL) (maxL, cntL) (minR, refR) (maxR, cntR); ref >= 0 is an
+// interior node, ref < 0 a run of cnt entries starting at ~ref.  entry = class << 30 | index in the set.
+// ---------------------------------------------------------------------------------------------------------
+struct SubRay { V3 om, op, rcp; float lo[3], hi[3]; bool par[3]; };
+
+DEVI void sub_child(const SubRay& q, const Ray& r, float4 mn, float4 mx, float& tn, float& tf) {
+    float a0 = (mn.x - q.op.x) * q.rcp.x, b0 = (mx.x - q.om.x) * q.rcp.x;
+    float a1 = (mn.y - q.op.y) * q.rcp.y, b1 = (mx.y - q.om.y) * q.rcp.y;
+    float a2 = (mn.z - q.op.z) * q.rcp.z, b2 = (mx.z - q.om.z) * q.rcp.z;
+    float n0 = fminf(a0, b0), f0 = fmaxf(a0, b0), n1 = fminf(a1, b1), f1 = fmaxf(a1, b1), n2 = fminf(a2, b2), f2 = fmaxf(a2, b2);
+    // a direction component too small to divide by: inside the padded slab -> no constraint, outside -> miss
+    if (q.par[0]) { bool in = !(r.o.x < mn.x - (q.op.x - r.o.x)) && !(r.o.x > mx.x + (q.op.x - r.o.x)); n0 = in ? -INFINITY : INFINITY; f0 = in ? INFINITY : -INFINITY; }
+    if (q.par[1]) { bool in = !(r.o.y < mn.y - (q.op.y - r.o.y)) && !(r.o.y > mx.y + (q.op.y - r.o.y)); n1 = in ? -INFINITY : INFINITY; f1 = in ? INFINITY : -INFINITY; }
+    if (q.par[2]) { bool in = !(r.o.z < mn.z - (q.op.z - r.o.z)) && !(r.o.z > mx.z + (q.op.z - r.o.z)); n2 = in ? -INFINITY : INFINITY; f2 = in ? INFINITY : -INFINITY; }
+    tn = fmaxf(fmaxf(n0, n1), n2);
+    tf = fminf(fminf(f0, f1), f2);
+    float E = 2e-6f * fmaxf(fabsf(tn), fabsf(tf));
+    if (!(E < INFINITY)) E = 0.0f;                   // infinite bounds need no slack (and inf - inf must not appear)
+    tn -= E; tf += E;
+}
+
+template <bool ANY>
+DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, const Ray& r, bool mb, bool leaf_rule,
+                    int* __restrict__ stack, Best& best) {
+    SubRay q;
+    {
+        V3 dc = r.o - mk(sc.center[0], sc.center[1], sc.center[2]);
+        float pad = 2e-5f * (__builtin_amdgcn_sqrtf(dot(dc, dc)) + sc.radius) + 1e-6f * sc.radius;
+        if (!(pad >= 0.0f)) pad = INFINITY;          // NaN origin: nothing may be skipped
+        q.om = mk(r.o.x - pad, r.o.y - pad, r.o.z - pad); q.op = mk(r.o.x + pad, r.o.y + pad, r.o.z + pad);
+        q.par[0] = !(fabsf(r.d.x) > 1e-12f); q.par[1] = !(fabsf(r.d.y) > 1e-12f); q.par[2] = !(fabsf(r.d.z) > 1e-12f);
+        q.rcp = mk(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
+    }
+    float best_t = leaf_rule ? INFINITY : FLT_MAX;
+    unsigned best_key = 0u; bool has = false;
+    int sp = 0, node = root;
+    for (;;) {
+        const float4* __restrict__ nd = sc.sub_nodes + 4 * (size_t)node;
+        float4 lmn = nd[0], lmx = nd[1], rmn = nd[2], rmx = nd[3];
+        float ltn, ltf, rtn, rtf;
+        sub_child(q, r, lmn, lmx, ltn, ltf);
+        sub_child(q, r, rmn, rmx, rtn, rtf);
+        // skip only on a certain miss; any NaN makes the comparisons false and the child is visited
+        bool goL = !(ltn > ltf) && !(ltf < 0.0f) && !(ltn > best_t);
+        bool goR = !(rtn > rtf) && !(rtf < 0.0f) && !(rtn > best_t);
+        int refL = f2i(lmn.w), refR = f2i(rmn.w), cntL = f2i(lmx.w), cntR = f2i(rmx.w);
+        // entry runs are tested on the spot, interior children are descended into (nearer first)
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const bool go = side ? goR : goL; const int ref = side ? refR : refL, cnt = side ? cntR : cntL;
+            if (go && ref < 0) {
+                const int first = ~ref;
+                for (int e = first; e < first + cnt; ++e) {
+                    const unsigned entry = (unsigned)sc.sub_entries[e];
+                    const int cls = (int)(entry >> 30), idx = (int)(entry & 0x3fffffffu);
+                    float t; bool ok;
+                    if (cls == 0) ok = plane_test<false>(S.planes + 3 * idx, S.verts, nullptr, r, false, t, nullptr);
+                    else if (cls == 1) ok = cube_test<false>(S.cubes + 6 * idx, r, mb, false, t, nullptr);
+                    else ok = sphere_test<false>(S.spheres + 2 * idx, r, mb, false, t, nullptr);
+                    if (ok && (!leaf_rule || t >= 0.0f) && (t < best_t || (has && t == best_t && entry < best_key))) {
+                        has = true; best_t = t; best_key = entry; best.t = t; best.cls = cls; best.idx = idx;
+                        if (ANY) return true;
+                    }
+                }
+            }
+        }
+        const bool inL = goL && refL >= 0 && !(ltn > best_t), inR = goR && refR >= 0 && !(rtn > best_t);
+        if (inL && inR) {
+            const bool leftFirst = !(rtn < ltn);
+            stack[sp * RT_BLOCK] = leftFirst ? refR : refL; ++sp;
+            node = leftFirst ? refL : refR;
+        } else if (inL) node = refL;
+        else if (inR) node = refR;
+        else {
+            if (sp == 0) break;
+            --sp; node = stack[sp * RT_BLOCK];
+        }
+    }
+    return has;
+}
+
+// Closest hit of a group of primitives: through its second-level hierarchy when it has one, else one by one.
+template <bool ANY>
+DEVI bool test_group(const DevScene& sc, const DevPrimSet& S, const Ray& r, bool mb, int p0, int pn, int c0, int cn, int s0, int sn,
+                     int sub_root, bool leaf_rule, int* __restrict__ stack, Best& best) {
+    if (sub_root >= 0) return sub_trace<ANY>(sc, S, sub_root, r, mb, leaf_rule, stack, best);
+    return test_prims<ANY>(S, r, mb, p0, pn, c0, cn, s0, sn, leaf_rule, best);
+}
+
 // BVHNode::intersect (bvh.cpp:35-105) or Raytracer::unacceleratedIntersection (raytracer.cpp:202-256).
 // The reference visits both children of every node whose box is hit and keeps the LAST leaf hit it pushed;
 // walking the nodes right child first and stopping at the first leaf that yields a hit gives the same answer.
@@ -344,7 +444,7 @@ DEVI bool test_prims(const DevPrimSet& S, const Ray& r, bool mb, int p0, int pn,
 // with_fallback: raytracer.cpp:424,484 - a secondary ray that misses the BVH is retried over every primitive.
 template <bool ANY>
 DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict__ nodes, const int4* __restrict__ leaves,
-                const Ray& r, bool with_fallback, Best& best) {
+                int* __restrict__ stack, const Ray& r, bool with_fallback, Best& best) {
     const bool mb = f.motion_blur != 0;
     if (f.use_bvh) {
         int i = 0;
@@ -360,15 +460,17 @@ DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict_
             ++i;
             if (leaf >= 0) {
                 int4 l0 = leaves[2 * leaf], l1 = leaves[2 * leaf + 1];
-                if (test_prims<ANY>(sc.leafset, r, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, true, best)) { best.fileset = 0; return true; }
+                if (test_group<ANY>(sc, sc.leafset, r, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, true, stack, best)) { best.fileset = 0; return true; }
             }
         }
         if (!with_fallback) return false;
         best.fileset = 1;
-        return test_prims<false>(sc.fileset, r, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres, false, best);
+        return test_group<false>(sc, sc.fileset, r, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
+                                 sc.file_sub_root, false, stack, best);
     }
     best.fileset = 1;
-    return test_prims<ANY>(sc.fileset, r, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres, false, best);
+    return test_group<ANY>(sc, sc.fileset, r, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
+                           sc.file_sub_root, false, stack, best);
 }
 
 DEVI void full_hit(const DevScene& sc, const DevFrame& f, const Ray& r, const Best& best, HitOut& h) {
@@ -491,6 +593,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, DevFrame f, De
     extern __shared__ float4 s_mem[];
     float4* s_nodes = s_mem;
     int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
+    int* s_stack = (int*)(s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves) + threadIdx.x;   // [depth][thread]
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
     const int count = PRIMARY ? f.pix_count : min(w.ctr[RT_C_LINK_CNT + level], w.link_off[level + 1] - w.link_off[level]);
     if ((int)(blockIdx.x * blockDim.x) >= count) return;               // whole workgroup idle
@@ -524,7 +627,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, DevFrame f, De
         }
         if (PRIMARY && active) ++n_primary;
         Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
-        bool hit = active && trace<false>(sc, f, s_nodes, s_leaves, r, !PRIMARY && f.fallback_full, best);
+        bool hit = active && trace<false>(sc, f, s_nodes, s_leaves, s_stack, r, !PRIMARY && f.fallback_full, best);
 
         // one node per hit
         unsigned long long hm = __ballot(hit);
@@ -641,6 +744,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, DevFrame f, De
     extern __shared__ float4 s_mem[];
     float4* s_nodes = s_mem;
     int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
+    int* s_stack = (int*)(s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves) + threadIdx.x;   // [depth][thread]
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
     __shared__ int s_first[RT_MAX_LEVELS];                              // dense index of each level's first hit
     if (threadIdx.x == 0) {
@@ -690,7 +794,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, DevFrame f, De
                 V3 nrm = mk(b.x, b.y, b.z);
                 sr.d = normalise(mk(lt.x - p.x, lt.y - p.y, lt.z - p.z));
                 sr.o = p + nrm * 1e-2f;                                  // raytracer.cpp:515: unflipped geometric normal
-                unblocked = !trace<true>(sc, f, s_nodes, s_leaves, sr, false, best);
+                unblocked = !trace<true>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
             } else {
                 uint32_t path = (uint32_t)f2i(w.n_c[node].z);
                 uint4 q = philox(path, (uint32_t)l, (uint32_t)j, STREAM_SHADOW, f.seed, 0x52541u);
@@ -701,7 +805,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, DevFrame f, De
                 sr.o = p + ld * 0.001f;                                  // raytracer.cpp:549
                 sr.d = ld;
                 float lightDist = len_ref(h2l);                          // raytracer.cpp:553
-                bool hit = trace<false>(sc, f, s_nodes, s_leaves, sr, false, best);
+                bool hit = trace<false>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
                 unblocked = !(hit && best.t < lightDist);                // raytracer.cpp:564
             }
         }
@@ -870,8 +974,13 @@ __global__ void k_assemble(const unsigned char* __restrict__ tiles, int world, i
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
+// LDS per workgroup: the first-level nodes and leaf records (BVH mode) and, when any group of primitives has a
+// second-level hierarchy, one traversal stack per thread.  The kernels index from n_nodes / n_leaves, which the
+// context zeroes when no BVH is uploaded.
 static size_t bvh_lds_bytes(const DevScene& sc, const DevFrame& f) {
-    return f.use_bvh ? (size_t)(2 * sc.n_nodes + 2 * sc.n_leaves) * 16 : 16;
+    size_t b = (size_t)(2 * sc.n_nodes + 2 * sc.n_leaves) * 16;
+    if (sc.sub_nodes) b += (size_t)RT_BLOCK * RT_SUB_STACK * sizeof(int);
+    return b ? b : 16;
 }
 
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {

@@ -12,6 +12,9 @@
 #define RT_MAX_LEVELS  34            // recursion levels 0..32 plus one end marker
 #define RT_MAX_LDS_NODES   1024      // BVH nodes staged in LDS (32 B each)
 #define RT_MAX_LDS_LEAVES  512       // leaf records staged in LDS (32 B each)
+#define RT_SUB_LEAF        4         // second-level hierarchy: primitives per entry run
+#define RT_SUB_MIN_GROUP   8         // groups of at most this many primitives are tested one by one
+#define RT_SUB_STACK       26        // second-level traversal stack entries per thread (LDS)
 
 // ---- primitives ---------------------------------------------------------------------------------------
 // A primitive set is one ordering of the scene's primitives: leaf order (BVH traversal) or file order
@@ -40,7 +43,9 @@ struct DevPrimSet {
 // light    : (x, y, z, radiant intensity)
 // BVH node : 2 words (min.xyz, bits skip) (max.xyz, bits leaf | -1), laid out in the order a traversal that
 //            visits the right child first meets them; skip = index of the next node once this subtree is done.
-// leaf     : 2 words of ints (plane_first, plane_count, cube_first, cube_count) (sphere_first, sphere_count, 0, 0)
+// leaf     : 2 words of ints (plane_first, plane_count, cube_first, cube_count)
+//            (sphere_first, sphere_count, second-level root | -1, 0)
+// second-level node : 4 words, see sub_trace in rt_kernels.hip; entries: class << 30 | index in the primitive set
 struct DevScene {
     const float4* nodes;  int n_nodes;
     const int4* leaves;   int n_leaves;
@@ -51,6 +56,10 @@ struct DevScene {
     const int4* tex_desc;
     const float4* texels;
     const float4* lights; int n_lights;
+    const float4* sub_nodes;       // second-level hierarchies of all groups (NULL when no group has one)
+    const int* sub_entries;
+    int file_sub_root;             // second-level root over the whole file-order set, or -1
+    float center[3], radius;       // sphere around the true bounds of everything in the scene
 };
 
 struct DevFrame {

@@ -101,28 +101,45 @@ def glass_scene(res=(240, 135), textured=False) -> str:
     return scene_text(cams, lights, spheres, cubes, planes)
 
 
+GROUND_DIFFUSE = (0.0, 0.12389342486858368, 0.002572941593825817)
+REF_LIGHT = (4.076245307922363, 1.0054539442062378, 5.903861999511719)
+
+
+def random_prims(n_prims: int, seed: int = 42, moving=False, transparent_frac=0.0, extent=20.0, rmin=0.02, rmax=0.1):
+    """The random population behind random_scene / random_scene_arrays, vectorised: one table of 14 float64
+    columns per primitive (centre xyz, size, diffuse rgb, transparency, end z offset, rotation xyz, is_cube, pad)."""
+    rng = np.random.default_rng(seed)
+    t = np.zeros((n_prims, 14), dtype=np.float64)
+    t[:, 0] = rng.uniform(-extent, extent, n_prims)
+    t[:, 1] = rng.uniform(-extent, extent, n_prims)
+    t[:, 2] = rng.uniform(0.0, 10.0, n_prims)
+    t[:, 3] = rng.uniform(rmin, rmax, n_prims)
+    t[:, 4:7] = rng.uniform(0.0, 1.0, (n_prims, 3))
+    t[:, 7] = np.where(rng.uniform(0.0, 1.0, n_prims) < transparent_frac, 0.6, 0.0)
+    t[:, 8] = rng.uniform(0.0, 1.0, n_prims) if moving else 0.0
+    t[:, 9:12] = rng.uniform(0.0, 2.0 * math.pi, (n_prims, 3))
+    t[:, 12] = np.arange(n_prims) % 2
+    return t
+
+
 def random_scene(n_prims: int, seed: int = 42, res=(1920, 1080), with_ground=True, moving=False,
                  transparent_frac=0.0, extent=20.0, rmin=0.02, rmax=0.1) -> str:
     """Random spheres and cubes over a ground plane: 50 % spheres r in U[rmin,rmax], 50 % cubes scale in
     U[rmin,rmax] with rotation in U[0,2pi)^3, centres U[-extent,extent]^2 x [0,10], diffuse U[0,1]^3,
     specular 0.3, shininess 64; camera and light of the reference's scene.json."""
-    rng = np.random.default_rng(seed)
+    t = random_prims(n_prims, seed, moving, transparent_frac, extent, rmin, rmax)
     cams = [camera(res=res)]
-    lights = [light((4.076245307922363, 1.0054539442062378, 5.903861999511719), 1000.0)]
+    lights = [light(REF_LIGHT, 1000.0)]
     spheres, cubes = [], []
-    for i in range(n_prims):
-        c = (rng.uniform(-extent, extent), rng.uniform(-extent, extent), rng.uniform(0.0, 10.0))
-        r = rng.uniform(rmin, rmax)
-        diff = rng.uniform(0.0, 1.0, 3)
-        tr = 0.6 if rng.uniform() < transparent_frac else 0.0
-        m = material(diff, (0.3, 0.3, 0.3), 64.0, tr, 1.5)
-        end = (c[0], c[1], c[2] + rng.uniform(0.0, 1.0)) if moving else None
-        if i % 2 == 0:
-            spheres.append(sphere(c, r, m, end=end))
+    for row in t:
+        c = (row[0], row[1], row[2])
+        m = material(row[4:7], (0.3, 0.3, 0.3), 64.0, row[7], 1.5)
+        end = (c[0], c[1], c[2] + row[8]) if moving else None
+        if row[12] == 0:
+            spheres.append(sphere(c, row[3], m, end=end))
         else:
-            rot = rng.uniform(0.0, 2.0 * math.pi, 3)
-            cubes.append(cube(c, r, m, rotation=rot, end=end))
-    planes = [ground(50.0, 0.0, material((0.0, 0.12389342486858368, 0.002572941593825817)))] if with_ground else []
+            cubes.append(cube(c, row[3], m, rotation=row[9:12], end=end))
+    planes = [ground(50.0, 0.0, material(GROUND_DIFFUSE))] if with_ground else []
     return scene_text(cams, lights, spheres, cubes, planes)
 
 

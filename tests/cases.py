@@ -35,6 +35,9 @@ SCENES = {
     "glass_tex": lambda: sg.glass_scene((200, 112), True),
     "cluster16": lambda: sg.cluster_scene(16, 7, (200, 112)),
     "rand200": lambda: sg.random_scene(200, 42, (160, 90), rmin=0.2, rmax=0.6, transparent_frac=0.2, moving=True),
+    # dense enough that the depth-8 tree's leaves hold tens of primitives (second-level hierarchy on the device)
+    "rand300m": lambda: sg.random_scene(300, 5, (96, 54), rmin=0.15, rmax=0.45, moving=True, extent=6.0),
+    "rand2k": lambda: sg.random_scene(2000, 11, (128, 72), rmin=0.15, rmax=0.5, transparent_frac=0.15, moving=True, extent=12.0),
 }
 
 # Deterministic flag sets: the image is a pure function of scene + flags; the bar is +-1 LSB per channel.
@@ -59,6 +62,9 @@ DETERMINISTIC = [
     ("rand200", []),
     ("rand200", ["-u"]),
     ("rand200", ["-rd", "2", "-grs", "1"]),
+    ("rand2k", []),
+    ("rand2k", ["-u"]),
+    ("rand2k", ["-rd", "2", "-grs", "1"]),
 ]
 
 # Stochastic flag sets: judged by PSNR >= 40 dB between two high-sample renders (the golden one is the reference's).
@@ -69,6 +75,8 @@ STOCHASTIC = [
     ("ref", ["-m", "-mbs", "256"]),
     ("ref", ["-r", "-gr", "-grs", "256"]),
     ("glass_tex", ["-t", "-aa", "-aas", "256", "-r", "-grs", "1"]),
+    # moving primitives inside crowded leaves (second-level hierarchy over swept bounds)
+    ("rand300m", ["-m", "-mbs", "128", "-r", "-grs", "1"]),
     # the flag set of the 4K multi-sample configuration (4096 samples per pixel) on a small film
     ("ref120", ["-aa", "-aas", "16", "-gr", "-grs", "16", "-dof", "-dofs", "16", "-m", "-mbs", "16"]),
 ]

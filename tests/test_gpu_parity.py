@@ -172,3 +172,41 @@ def test_error_paths():
     with pytest.raises(api.RtError):
         r.set_shard(3, 2)
     r.close(); ls.close()
+
+
+# ---- large scenes: the second-level hierarchy ----------------------------------------------------------------
+
+@pytest.mark.parametrize("n,res,flags", [(20000, (960, 540), []), (20000, (960, 540), ["-u"]),
+                                         (20000, (480, 270), ["-rd", "2", "-grs", "1"]), (200000, (320, 180), [])])
+def test_second_level_hierarchy_changes_no_pixel(n, res, flags):
+    """Searching a crowded group through its hierarchy must give exactly the image of testing its primitives one
+    by one (the reference's leaf loop / brute-force loop), on scenes far larger than the oracle can render whole."""
+    table = sg.random_prims(n, 42, transparent_frac=0.1)
+    cfg, _ = api.parse_args(flags)
+    imgs = []
+    for min_group in (8, 1 << 40):
+        ls = api.ArrayScene(table, res)
+        r = api.Renderer(0)
+        r.set_option("second_level_min_group", min_group)
+        r.upload(ls, with_bvh=bool(cfg.bvh))
+        img, st = r.render(cfg)
+        imgs.append(img); r.close(); ls.close()
+    assert imgs[0].max() > 0
+    assert np.array_equal(imgs[0], imgs[1])
+
+
+def test_large_scene_windows_match_oracle():
+    """50 000 primitives at 1920x1080: the whole frame is out of the oracle's reach, pixel windows are not."""
+    n, res = 50000, (1920, 1080)
+    text = sg.random_scene(n, 42, res)
+    ls = api.ArrayScene(sg.random_prims(n, 42), res)
+    for flags in ([], ["-u"]):
+        cfg, _ = api.parse_args(flags)
+        r = api.Renderer(0); r.upload(ls, with_bvh=bool(cfg.bvh))
+        img, _ = r.render(cfg); r.close()
+        for (x0, y0) in [(950, 530), (1660, 190), (300, 900)]:
+            win = (x0, y0, x0 + 20, y0 + 12)
+            ref, _ = oracle.render(text, flags, window=win)
+            a, b = img[y0:y0 + 12, x0:x0 + 20].astype(np.int32), ref[y0:y0 + 12, x0:x0 + 20]
+            assert np.array_equal(a, b), f"{flags} window {win}: {(a != b).any(axis=2).sum()} pixels differ"
+    ls.close()
