@@ -143,9 +143,8 @@ typedef struct rt_config {
     /* additions (no counterpart in the reference) */
     uint32_t seed;                /* key of the counter-based generator; the reference never seeds rand() */
     int32_t fallback;             /* brute-force retry of secondary rays after a BVH miss (raytracer.cpp:424,484):
-                                     0 = auto (1 when the scene has <= 4096 primitives, else 2),
-                                     1 = over every primitive, exactly as the reference,
-                                     2 = only over primitives that stick out of their leaf box */
+                                     0 or 1 = over every primitive, exactly as the reference (default),
+                                     2 = skipped (faster, differs where the reference's retry finds a hit) */
 } rt_config;
 
 typedef struct rt_stats {

@@ -684,7 +684,9 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     f.soft_shadows = cfg->soft_shadows != 0; f.ss_samples = cfg->ss_samples; f.glossy = cfg->glossy_reflect != 0; f.gr_samples = cfg->gr_samples;
     f.anti_aliasing = cfg->anti_aliasing != 0; f.aa_n = AA; f.dof_on = cfg->dof != 0; f.dof_n = DOF; f.mb_on = cfg->motion_blur != 0; f.mb_n = MB;
     f.textures = cfg->textures != 0; f.use_bvh = cfg->bvh != 0; f.motion_blur = cfg->motion_blur != 0; f.max_depth = D;
-    int fb = cfg->fallback; if (fb == 0) fb = (n_prims <= 4096) ? 1 : 2;
+    // the retry is exact and, through the file-order set's hierarchy, cheap at any scene size: on unless opted out
+    int fb = cfg->fallback; if (fb == 0) fb = 1;
+    (void)n_prims;
     f.fallback_full = (fb == 1);
     f.light_radius = cfg->light_radius; f.seed = cfg->seed;
     f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y; f.n_local_tiles = (int)c->local_tiles.size(); f.local_tiles = c->d_local_tiles.p;
