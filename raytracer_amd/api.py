@@ -11,7 +11,9 @@ from pathlib import Path
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "librt_amd.so"
+import os
+
+LIB_PATH = Path(os.environ.get("RT_AMD_LIB", HERE / "librt_amd.so"))   # the override is a development aid
 TILE = 32
 
 RT_OK = 0

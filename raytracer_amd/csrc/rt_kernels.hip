@@ -12,6 +12,14 @@
 
 #define DEVI __device__ __forceinline__
 
+// minimum wavefronts per SIMD the register allocator must leave room for (second __launch_bounds__ argument)
+#ifndef RT_EXTEND_WAVES
+#define RT_EXTEND_WAVES 3
+#endif
+#ifndef RT_SHADOW_WAVES
+#define RT_SHADOW_WAVES 4
+#endif
+
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
@@ -75,9 +83,9 @@ DEVI V3 unit_sphere(float u, float v, float w) {
 DEVI V3 cone_direction(V3 dir, float angle, uint32_t r0, uint32_t r1) {
     float cosTheta = cosf(angle);
     float z = cosTheta + (1.0f - cosTheta) * ((float)(int)((r0 >> 1) % 1000u) / 1000.0f);
-    float phi = (float)((double)(2.0f) * M_PI * (double)((float)(int)((r1 >> 1) % 1000u) / 1000.0f));
+    float rev = (float)(int)((r1 >> 1) % 1000u) / 1000.0f;             // phi = 2 pi k / 1000, taken in revolutions
     float r = sqrtf(1.0f - z * z);
-    V3 rv = mk(r * cosf(phi), r * sinf(phi), z);
+    V3 rv = mk(r * __builtin_amdgcn_cosf(rev), r * __builtin_amdgcn_sinf(rev), z);
     V3 u = normalise(cross(mk(0.0f, 1.0f, 0.0f), dir));
     V3 v = cross(dir, u);
     V3 s = mk(rv.x * u.x + rv.y * v.x + rv.z * dir.x, rv.x * u.y + rv.y * v.y + rv.z * dir.y, rv.x * u.z + rv.y * v.z + rv.z * dir.z);
@@ -430,10 +438,11 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, const Ray
 }
 
 // Closest hit of a group of primitives: through its second-level hierarchy when it has one, else one by one.
-template <bool ANY>
+// SUB = the scene has at least one second-level hierarchy (kernels for small scenes are compiled without that code).
+template <bool ANY, bool SUB>
 DEVI bool test_group(const DevScene& sc, const DevPrimSet& S, const Ray& r, bool mb, int p0, int pn, int c0, int cn, int s0, int sn,
                      int sub_root, bool leaf_rule, int* __restrict__ stack, Best& best) {
-    if (sub_root >= 0) return sub_trace<ANY>(sc, S, sub_root, r, mb, leaf_rule, stack, best);
+    if (SUB && sub_root >= 0) return sub_trace<ANY>(sc, S, sub_root, r, mb, leaf_rule, stack, best);
     return test_prims<ANY>(S, r, mb, p0, pn, c0, cn, s0, sn, leaf_rule, best);
 }
 
@@ -442,7 +451,7 @@ DEVI bool test_group(const DevScene& sc, const DevPrimSet& S, const Ray& r, bool
 // walking the nodes right child first and stopping at the first leaf that yields a hit gives the same answer.
 // The node array is laid out in that order with skip links, so the walk needs no stack.
 // with_fallback: raytracer.cpp:424,484 - a secondary ray that misses the BVH is retried over every primitive.
-template <bool ANY>
+template <bool ANY, bool SUB>
 DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict__ nodes, const int4* __restrict__ leaves,
                 int* __restrict__ stack, const Ray& r, bool with_fallback, Best& best) {
     const bool mb = f.motion_blur != 0;
@@ -460,16 +469,16 @@ DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict_
             ++i;
             if (leaf >= 0) {
                 int4 l0 = leaves[2 * leaf], l1 = leaves[2 * leaf + 1];
-                if (test_group<ANY>(sc, sc.leafset, r, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, true, stack, best)) { best.fileset = 0; return true; }
+                if (test_group<ANY, SUB>(sc, sc.leafset, r, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, true, stack, best)) { best.fileset = 0; return true; }
             }
         }
         if (!with_fallback) return false;
         best.fileset = 1;
-        return test_group<false>(sc, sc.fileset, r, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
+        return test_group<false, SUB>(sc, sc.fileset, r, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
                                  sc.file_sub_root, false, stack, best);
     }
     best.fileset = 1;
-    return test_group<ANY>(sc, sc.fileset, r, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
+    return test_group<ANY, SUB>(sc, sc.fileset, r, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
                            sc.file_sub_root, false, stack, best);
 }
 
@@ -562,10 +571,11 @@ DEVI bool generate_primary(const DevFrame& f, int i, Ray& r, uint32_t& path, int
         float lx = 2.0f * u01(q.x) - 1.0f, ly = 2.0f * u01(q.y) - 1.0f;
         float sx = 0.0f, sy = 0.0f;
         if (!(lx == 0.0f && ly == 0.0f)) {
-            float theta, rr;
-            if (fabsf(lx) > fabsf(ly)) { rr = lx; theta = (float)((M_PI / 4.0) * (double)(ly / lx)); }
-            else { rr = ly; theta = (float)((M_PI / 2.0) - (M_PI / 4.0) * (double)(lx / ly)); }
-            sx = rr * cosf(theta); sy = rr * sinf(theta);
+            // camera.cpp:299-311: theta = (pi/4)(y/x) or pi/2 - (pi/4)(x/y); here in revolutions for v_sin/v_cos
+            float rev, rr;
+            if (fabsf(lx) > fabsf(ly)) { rr = lx; rev = 0.125f * (ly / lx); }
+            else { rr = ly; rev = 0.25f - 0.125f * (lx / ly); }
+            sx = rr * __builtin_amdgcn_cosf(rev); sy = rr * __builtin_amdgcn_sinf(rev);
         }
         sx *= f.lens_radius; sy *= f.lens_radius;
         V3 right = mk(f.right[0], f.right[1], f.right[2]), up = mk(f.up[0], f.up[1], f.up[2]);
@@ -588,8 +598,8 @@ DEVI bool generate_primary(const DevFrame& f, int i, Ray& r, uint32_t& path, int
 // extend: trace one ray per lane to the hit the reference would report, append a hit-tree node, and spawn the
 // reflection / refraction rays of the next level (raytracer.cpp:144-164 for primaries, :373-498 for the spawn).
 // ---------------------------------------------------------------------------------------------------------
-template <bool PRIMARY>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, DevFrame f, DevWork w, int level) {
+template <bool PRIMARY, bool SUB>
+__global__ __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) void k_extend(DevScene sc, DevFrame f, DevWork w, int level) {
     extern __shared__ float4 s_mem[];
     float4* s_nodes = s_mem;
     int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
@@ -627,7 +637,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, DevFrame f, De
         }
         if (PRIMARY && active) ++n_primary;
         Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
-        bool hit = active && trace<false>(sc, f, s_nodes, s_leaves, s_stack, r, !PRIMARY && f.fallback_full, best);
+        bool hit = active && trace<false, SUB>(sc, f, s_nodes, s_leaves, s_stack, r, !PRIMARY && f.fallback_full, best);
 
         // one node per hit
         unsigned long long hm = __ballot(hit);
@@ -740,7 +750,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DevScene sc, DevFrame f, De
 // blocks.  Soft shadows (raytracer.cpp:534-571): ss_samples rays to points in a ball around the light, blocked
 // when the reported hit is nearer than the sampled point.  Output = number of unblocked samples per (hit, light).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, DevFrame f, DevWork w) {
+template <bool SUB>
+__global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene sc, DevFrame f, DevWork w) {
     extern __shared__ float4 s_mem[];
     float4* s_nodes = s_mem;
     int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
@@ -794,7 +805,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, DevFrame f, De
                 V3 nrm = mk(b.x, b.y, b.z);
                 sr.d = normalise(mk(lt.x - p.x, lt.y - p.y, lt.z - p.z));
                 sr.o = p + nrm * 1e-2f;                                  // raytracer.cpp:515: unflipped geometric normal
-                unblocked = !trace<true>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
+                unblocked = !trace<true, SUB>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
             } else {
                 uint32_t path = (uint32_t)f2i(w.n_c[node].z);
                 uint4 q = philox(path, (uint32_t)l, (uint32_t)j, STREAM_SHADOW, f.seed, 0x52541u);
@@ -805,7 +816,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shadow(DevScene sc, DevFrame f, De
                 sr.o = p + ld * 0.001f;                                  // raytracer.cpp:549
                 sr.d = ld;
                 float lightDist = len_ref(h2l);                          // raytracer.cpp:553
-                bool hit = trace<false>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
+                bool hit = trace<false, SUB>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
                 unblocked = !(hit && best.t < lightDist);                // raytracer.cpp:564
             }
         }
@@ -985,12 +996,19 @@ static size_t bvh_lds_bytes(const DevScene& sc, const DevFrame& f) {
 
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {
     size_t lds = bvh_lds_bytes(sc, f);
-    if (level == 0) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
-    else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+    const bool sub = sc.sub_nodes != nullptr;
+    if (level == 0) {
+        if (sub) hipLaunchKernelGGL((k_extend<true, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+        else hipLaunchKernelGGL((k_extend<true, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+    } else {
+        if (sub) hipLaunchKernelGGL((k_extend<false, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+        else hipLaunchKernelGGL((k_extend<false, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+    }
 }
 
 void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid) {
-    hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w);
+    if (sc.sub_nodes) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w);
+    else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w);
 }
 
 void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {

@@ -12,9 +12,9 @@ def find(pattern):
 
 
 def short(name):
-    for k in ("k_extend<true>", "k_extend<false>", "k_shadow", "k_shade", "k_finalize", "k_level_begin", "k_assemble"):
+    for k in ("k_extend<true", "k_extend<false", "k_shadow", "k_shade", "k_finalize", "k_assemble"):
         if k in name:
-            return k
+            return k + (">" if k.startswith("k_extend") else "")
     return name.split("(")[0][-60:]
 
 
