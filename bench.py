@@ -33,6 +33,9 @@ WORKLOADS = {
     # BASELINE.json configs[1]; "-s" in that text is the reference's -ss (config.cpp:15)
     "config2": dict(scene="ref", res=(1920, 1080), flags=["-r", "-rd", "4", "-ss", "-sss", "16"]),
     "config1": dict(scene="ref", res=(1920, 1080), flags=[]),
+    # BASELINE configs[2], synthetic part: 1M random spheres/cubes over a ground plane (seed 42), BVH on
+    "config3": dict(scene="random", n=1_000_000, res=(1920, 1080), flags=[]),
+    "config3u": dict(scene="random", n=1_000_000, res=(1920, 1080), flags=["-u"]),
     "config4": dict(scene="ref", res=(3840, 2160), flags=["-aa", "-aas", "16", "-gr", "-grs", "16", "-dof", "-dofs", "16", "-m", "-mbs", "16"]),
 }
 HBM_PEAK_GBS = 8000.0
@@ -126,10 +129,14 @@ def main():
     wl = WORKLOADS[args.workload]
     W, H = wl["res"]
     # scene text and flags come from rank 0 (one broadcast per frame set)
-    payload = json.dumps({"text": cases.reference_scene(W, H), "flags": wl["flags"]}).encode() if rank == 0 else None
+    payload = json.dumps({"text": cases.reference_scene(W, H) if wl["scene"] == "ref" else None, "flags": wl["flags"]}).encode() if rank == 0 else None
     payload = json.loads(rdist.broadcast_bytes(payload, 0, dev if (world > 1 and args.backend != "gloo") else None).decode())
     cfg, _ = api.parse_args(payload["flags"])
-    ls = api.LoadedScene(payload["text"], cfg, str(cases.TEXTURES))
+    if wl["scene"] == "ref":
+        ls = api.LoadedScene(payload["text"], cfg, str(cases.TEXTURES))
+    else:       # generated in-process from the seed on every rank (the population is a pure function of it)
+        from raytracer_amd import scenegen as sg
+        ls = api.ArrayScene(sg.random_prims(wl["n"], 42), (W, H))
     r = api.Renderer(local, workspace_bytes=16 << 30)
     r.upload(ls, with_bvh=bool(cfg.bvh))
     r.set_shard(rank, world)
@@ -202,11 +209,12 @@ def main():
         final = (image if world > 1 else block).cpu().numpy()
         lit = float((final.reshape(-1, 3).sum(axis=1) > 0).mean())
         line = {
-            "metric": "rays/sec (all ray types), 1080p scene.json",
+            "metric": "rays/sec (all ray types), 1080p scene.json" if args.workload == "config2" else f"rays/sec (all ray types), {args.workload}",
             "value": rays_total / (elapsed / args.steps), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic: the reference's own ASCII/scene.json (committed as a fixture), no dataset",
-            "config": {"workload": f"{args.workload}: scene.json {W}x{H}, flags {' '.join(wl['flags']) or '(none)'}",
+            "data": "synthetic: the reference's own ASCII/scene.json (committed as a fixture), no dataset" if wl["scene"] == "ref"
+                    else f"synthetic: {wl['n']} random spheres/cubes (seed 42) over a ground plane, generated in-process",
+            "config": {"workload": f"{args.workload}: {'scene.json' if wl['scene'] == 'ref' else str(wl['n']) + ' random primitives'} {W}x{H}, flags {' '.join(wl['flags']) or '(none)'}",
                        "spp": cfg.samples_per_pixel(), "tiles": "32x32 interleaved, rank = (tx+ty) % N",
                        "frame_ms_device_events": dev_ms / args.steps,
                        "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3],
