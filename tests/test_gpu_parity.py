@@ -210,3 +210,19 @@ def test_large_scene_windows_match_oracle():
             a, b = img[y0:y0 + 12, x0:x0 + 20].astype(np.int32), ref[y0:y0 + 12, x0:x0 + 20]
             assert np.array_equal(a, b), f"{flags} window {win}: {(a != b).any(axis=2).sum()} pixels differ"
     ls.close()
+
+
+def test_randomised_scenes_and_flags_match_oracle(textures_dir):
+    """80 random small scenes (all primitive classes, tilted shuffled n-gons, transparency, several lights, textures,
+    moving objects) x random deterministic flag sets: images bit-exact, reference-equivalent ray counts equal."""
+    import sys
+    sys.path.insert(0, str(cases.ROOT / "tools"))
+    import fuzz_parity
+    rng = np.random.default_rng(2025)
+    for k in range(80):
+        text = fuzz_parity.random_scene(rng, (96, 54)); flags = fuzz_parity.random_flags(rng)
+        ref, ost = oracle.render(text, flags, textures_dir)
+        img, st = api.render_scene_text(text, flags, textures_dir)
+        assert np.array_equal(img.astype(np.int32), ref), f"case {k} flags {flags}: {(img != ref).any(axis=2).sum()} pixels differ"
+        assert (st.primary_rays, st.shadow_rays_ref, st.reflection_rays_ref, st.refraction_rays_ref) == \
+               (ost.primary, ost.shadow, ost.reflection, ost.refraction), f"case {k} flags {flags}: ray counts"
