@@ -128,15 +128,19 @@ def main():
 
     wl = WORKLOADS[args.workload]
     W, H = wl["res"]
-    # scene text and flags come from rank 0 (one broadcast per frame set)
-    payload = json.dumps({"text": cases.reference_scene(W, H) if wl["scene"] == "ref" else None, "flags": wl["flags"]}).encode() if rank == 0 else None
-    payload = json.loads(rdist.broadcast_bytes(payload, 0, dev if (world > 1 and args.backend != "gloo") else None).decode())
-    cfg, _ = api.parse_args(payload["flags"])
-    if wl["scene"] == "ref":
-        ls = api.LoadedScene(payload["text"], cfg, str(cases.TEXTURES))
-    else:       # generated in-process from the seed on every rank (the population is a pure function of it)
-        from raytracer_amd import scenegen as sg
-        ls = api.ArrayScene(sg.random_prims(wl["n"], 42), (W, H))
+    # Rank 0 parses the scene and builds the BVH on its host; flags and the flat scene/BVH arrays are broadcast once
+    # per frame set (over RCCL with the nccl backend), every rank uploads its copy.
+    on_dev = dev if (world > 1 and args.backend != "gloo") else None
+    flags = json.loads(rdist.broadcast_bytes(json.dumps(wl["flags"]).encode() if rank == 0 else None, 0, on_dev).decode())
+    cfg, _ = api.parse_args(flags)
+    ls = None
+    if rank == 0:
+        if wl["scene"] == "ref":
+            ls = api.LoadedScene(cases.reference_scene(W, H), cfg, str(cases.TEXTURES))
+        else:
+            from raytracer_amd import scenegen as sg
+            ls = api.ArrayScene(sg.random_prims(wl["n"], 42), (W, H))
+    ls = rdist.broadcast_scene(ls, bool(cfg.bvh), 0, on_dev)
     r = api.Renderer(local, workspace_bytes=16 << 30)
     r.upload(ls, with_bvh=bool(cfg.bvh))
     r.set_shard(rank, world)

@@ -299,6 +299,96 @@ class ArrayScene(LoadedScene):
             lib().rt_host_free_bvh(C.byref(self._bvh)); self._bvh = None
 
 
+# ---- one flat byte blob per scene: what rank 0 broadcasts to the other ranks -----------------------------------
+
+_BLOB_MAGIC = 0x52544231      # "RTB1"
+
+
+def pack_scene(ls: "LoadedScene", with_bvh: bool = True) -> np.ndarray:
+    """Serialises the C-ABI arrays of a loaded scene (and its host-built BVH) into one uint8 array:
+    int64 header [magic, n_sections, (offset, nbytes) per section] followed by the raw arrays."""
+    sc = ls.scene
+
+    def raw(ptr, count, ctype):
+        if not count:
+            return np.zeros(0, dtype=np.uint8)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * C.sizeof(ctype),)).copy()
+
+    tex_meta = np.array([[sc.textures[i].width, sc.textures[i].height] for i in range(sc.n_textures)], dtype=np.int32).reshape(-1)
+    tex_data = [raw(sc.textures[i].rgb, sc.textures[i].width * sc.textures[i].height * 3, C.c_int32) for i in range(sc.n_textures)]
+    sections = [np.frombuffer(bytes(sc.camera), dtype=np.uint8), raw(sc.lights, sc.n_lights, Light), raw(sc.spheres, sc.n_spheres, Sphere),
+                raw(sc.cubes, sc.n_cubes, Cube), raw(sc.planes, sc.n_planes, Plane), raw(sc.plane_verts, sc.n_plane_verts * 3, C.c_float),
+                tex_meta.view(np.uint8), np.concatenate(tex_data) if tex_data else np.zeros(0, dtype=np.uint8)]
+    if with_bvh:
+        b = ls.bvh()
+        sections += [raw(b.nodes, b.n_nodes, BvhNode), raw(b.prim_ids, b.n_prim_ids, C.c_int32)]
+    else:
+        sections += [np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.uint8)]
+    head = np.zeros(2 + 2 * len(sections), dtype=np.int64)
+    head[0], head[1] = _BLOB_MAGIC, len(sections)
+    off = head.nbytes
+    for i, sec in enumerate(sections):
+        head[2 + 2 * i], head[3 + 2 * i] = off, sec.nbytes
+        off += (sec.nbytes + 15) // 16 * 16
+    blob = np.zeros(off, dtype=np.uint8)
+    blob[:head.nbytes] = head.view(np.uint8)
+    for i, sec in enumerate(sections):
+        blob[head[2 + 2 * i]:head[2 + 2 * i] + sec.nbytes] = sec
+    return blob
+
+
+class PackedScene(LoadedScene):
+    """A scene (and BVH) rebuilt from pack_scene's blob: the receiving side of the scene broadcast."""
+
+    def __init__(self, blob: np.ndarray):
+        self._hs = None; self._bvh = None
+        self._blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        head = self._blob[:16].view(np.int64)
+        if int(head[0]) != _BLOB_MAGIC:
+            raise RtError(-1, "not a scene blob")
+        n = int(head[1])
+        table = self._blob[16:16 + 16 * n].view(np.int64).reshape(n, 2)
+        sec = [self._blob[int(o):int(o) + int(b)] for o, b in table]
+        sc = Scene()
+        C.memmove(C.byref(sc.camera), sec[0].ctypes.data, C.sizeof(Camera))
+
+        def ptr(a, ctype):
+            return C.cast(a.ctypes.data, C.POINTER(ctype)) if a.nbytes else None
+
+        sc.n_lights = sec[1].nbytes // C.sizeof(Light); sc.lights = ptr(sec[1], Light)
+        sc.n_spheres = sec[2].nbytes // C.sizeof(Sphere); sc.spheres = ptr(sec[2], Sphere)
+        sc.n_cubes = sec[3].nbytes // C.sizeof(Cube); sc.cubes = ptr(sec[3], Cube)
+        sc.n_planes = sec[4].nbytes // C.sizeof(Plane); sc.planes = ptr(sec[4], Plane)
+        sc.n_plane_verts = sec[5].nbytes // 12; sc.plane_verts = ptr(sec[5], C.c_float)
+        meta = sec[6].view(np.int32).reshape(-1, 2)
+        self._tex = (Texture * max(1, len(meta)))()
+        off = 0
+        for i, (w, h) in enumerate(meta):
+            self._tex[i].width, self._tex[i].height = int(w), int(h)
+            self._tex[i].rgb = C.cast(sec[7].ctypes.data + off, C.POINTER(C.c_int32))
+            off += int(w) * int(h) * 12
+        sc.n_textures = len(meta); sc.textures = self._tex if len(meta) else None
+        self._scene = sc
+        self._packed_bvh = None
+        if sec[8].nbytes:
+            b = HostBvh()
+            b.nodes = ptr(sec[8], BvhNode); b.n_nodes = sec[8].nbytes // C.sizeof(BvhNode)
+            b.prim_ids = ptr(sec[9], C.c_int32); b.n_prim_ids = sec[9].nbytes // 4
+            self._packed_bvh = b
+
+    @property
+    def scene(self) -> Scene:
+        return self._scene
+
+    def bvh(self, max_depth: int = 8) -> HostBvh:
+        if self._packed_bvh is None:
+            raise RtError(-3, "the blob carries no BVH")
+        return self._packed_bvh
+
+    def close(self):
+        pass
+
+
 def camera_ray(cam: Camera, x: float, y: float) -> np.ndarray:
     out = (C.c_float * 6)()
     lib().rt_host_camera_ray(C.byref(cam), x, y, out)

@@ -55,3 +55,32 @@ def broadcast_bytes(data: bytes | None, src: int = 0, device: torch.device | Non
         buf = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
     dist.broadcast(buf, src)
     return bytes(buf.cpu().numpy().tobytes())
+
+
+def broadcast_array(arr, src: int = 0, device: torch.device | None = None):
+    """Broadcast one uint8 numpy array from `src` (other ranks pass None); returns the array on every rank.
+    With the nccl backend the bytes travel GPU to GPU over xGMI (`device` = this rank's GPU)."""
+    import numpy as np
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return arr
+    device = device or torch.device("cpu")
+    n = torch.tensor([arr.nbytes if dist.get_rank() == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, src)
+    if dist.get_rank() == src:
+        buf = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint8)).to(device)
+    else:
+        buf = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
+    dist.broadcast(buf, src)
+    return arr if dist.get_rank() == src else buf.cpu().numpy()
+
+
+def broadcast_scene(loaded, with_bvh: bool, src: int = 0, device: torch.device | None = None):
+    """The scene broadcast of the multi-GPU design: rank `src` has parsed the scene and built the BVH on its host
+    (`loaded`, an api.LoadedScene; other ranks pass None); every other rank receives the flat arrays once and
+    rebuilds the C-ABI view from them.  Returns an object usable with api.Renderer.upload on every rank."""
+    from . import api
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return loaded
+    blob = api.pack_scene(loaded, with_bvh) if dist.get_rank() == src else None
+    blob = broadcast_array(blob, src, device)
+    return loaded if dist.get_rank() == src else api.PackedScene(blob)

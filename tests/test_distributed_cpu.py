@@ -35,6 +35,14 @@ def _worker(rank: int, world: int, port: int, img: np.ndarray, out_path: str):
     assert (r, w) == (rank, world)
     text = rdist.broadcast_bytes(b"scene-bytes" if rank == 0 else None)
     assert text == b"scene-bytes"
+    # scene broadcast: rank 0 parses and builds, the others rebuild the C-ABI arrays from the blob
+    from raytracer_amd import scenegen as sg
+    cfg, _ = api.parse_args(["-t"])
+    mine = api.LoadedScene(sg.glass_scene((64, 36), True), cfg, str(cases.TEXTURES)) if rank == 0 else None
+    got = rdist.broadcast_scene(mine, True)
+    ref = api.LoadedScene(sg.glass_scene((64, 36), True), cfg, str(cases.TEXTURES))
+    assert bytes(api.pack_scene(got, True)) == bytes(api.pack_scene(ref, True))
+    assert got.scene.n_textures == 2 and got.bvh().n_nodes == ref.bvh().n_nodes
     block = torch.from_numpy(shard_block(img, rank, world))
     gathered = rdist.gather_blocks(block, dst=0)
     if rank == 0:

@@ -226,3 +226,15 @@ def test_randomised_scenes_and_flags_match_oracle(textures_dir):
         assert np.array_equal(img.astype(np.int32), ref), f"case {k} flags {flags}: {(img != ref).any(axis=2).sum()} pixels differ"
         assert (st.primary_rays, st.shadow_rays_ref, st.reflection_rays_ref, st.refraction_rays_ref) == \
                (ost.primary, ost.shadow, ost.reflection, ost.refraction), f"case {k} flags {flags}: ray counts"
+
+
+def test_scene_blob_round_trip_renders_identically(textures_dir):
+    """The arrays rank 0 broadcasts (api.pack_scene) rebuild a scene that renders to the same image."""
+    flags = ["-t", "-rd", "2", "-grs", "1"]
+    cfg, _ = api.parse_args(flags)
+    ls = api.LoadedScene(cases.SCENES["glass_tex"](), cfg, textures_dir)
+    ps = api.PackedScene(api.pack_scene(ls, True))
+    imgs = []
+    for s in (ls, ps):
+        r = api.Renderer(0); r.upload(s); imgs.append(r.render(cfg)[0]); r.close()
+    assert np.array_equal(imgs[0], imgs[1]) and imgs[0].max() > 0
