@@ -30,10 +30,10 @@ from raytracer_amd import api
 from raytracer_amd import dist as rdist
 
 WORKLOADS = {
-    # BASELINE.json configs[1]; "-s" in that text is the reference's -ss (config.cpp:15)
+    # the headline configuration: reflection/refraction depth 4 + 16-sample soft shadows (soft shadows are -ss, config.cpp:15)
     "config2": dict(scene="ref", res=(1920, 1080), flags=["-r", "-rd", "4", "-ss", "-sss", "16"]),
     "config1": dict(scene="ref", res=(1920, 1080), flags=[]),
-    # BASELINE configs[2], synthetic part: 1M random spheres/cubes over a ground plane (seed 42), BVH on
+    # large-scene configuration, synthetic part: 1M random spheres/cubes over a ground plane (seed 42), BVH on
     "config3": dict(scene="random", n=1_000_000, res=(1920, 1080), flags=[]),
     "config3u": dict(scene="random", n=1_000_000, res=(1920, 1080), flags=["-u"]),
     "config4": dict(scene="ref", res=(3840, 2160), flags=["-aa", "-aas", "16", "-gr", "-grs", "16", "-dof", "-dofs", "16", "-m", "-mbs", "16"]),
@@ -41,7 +41,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0
 
 
-# Algorithmic bytes per unit of work (DESIGN.md "Byte model"): what a wavefront pipeline with explicit ray and hit
+# Algorithmic bytes per unit of work: what a wavefront pipeline with explicit ray and hit
 # records has to move per ray, independent of how this implementation lays the records out.
 BYTES_PER_EXTEND_RAY = 120      # ray record 48 B written + read, hit record 12 B written + read
 BYTES_PER_SHADOW_RAY = 72       # shadow-ray record 32 B written + read, result 4 B written + read
