@@ -211,6 +211,17 @@ struct rt_ctx {
     DevBuf<unsigned char> out_tmp;
     unsigned long long last_batches = 0;
     std::vector<hipEvent_t> event_pool;
+    // Captured launch sequences of whole frames (rt_render_device without statistics), replayed with one
+    // hipGraphLaunch.  A frame is captured the second time it is asked for with the same configuration, output
+    // pointer and stream, i.e. once its buffers exist; anything that changes the scene or the shard drops them.
+    struct FrameGraph { rt_config cfg; void* out; hipStream_t stream; unsigned long long generation; bool warm; hipGraphExec_t exec; };
+    std::vector<FrameGraph> graphs;
+    unsigned long long generation = 0;
+    int use_graphs = 1;
+    void drop_graphs() {
+        for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        graphs.clear(); ++generation;
+    }
 
     int fail(int code, const char* fmt, ...) {
         char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -269,6 +280,7 @@ void rt_destroy(rt_ctx* c) {
     c->d_leaves.release(); c->d_tex_desc.release(); c->d_local_tiles.release(); c->n_uv.release(); c->n_pix.release();
     c->link.release(); c->ctr.release(); c->shadow.release(); c->stats.release(); c->out_tmp.release();
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    c->drop_graphs();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -276,6 +288,7 @@ void rt_destroy(rt_ctx* c) {
 int rt_set_stream(rt_ctx* c, void* hip_stream) {
     if (!c) return RT_ERR_ARG;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->drop_graphs();
     return RT_OK;
 }
 
@@ -286,6 +299,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
         c->sub_min_group = value > 0x7fffffff ? 0x7fffffff : (int)value;
         return RT_OK;
     }
+    if (std::strcmp(name, "graphs") == 0) { c->use_graphs = value != 0; c->drop_graphs(); return RT_OK; }
     return c->fail(RT_ERR_ARG, "unknown option %s", name);
 }
 
@@ -310,6 +324,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));     // previous frames may still read the old arrays
 
+    c->drop_graphs();
     c->camera = sc->camera;
     c->spheres.assign(sc->spheres, sc->spheres + sc->n_spheres);
     c->cubes.assign(sc->cubes, sc->cubes + sc->n_cubes);
@@ -487,6 +502,7 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->have_bvh = false;
+    c->drop_graphs();
     c->scene.n_nodes = 0; c->scene.n_leaves = 0;
     if (!nodes || n_nodes <= 0) return RT_OK;
     if (n_prim_ids < 0 || (n_prim_ids && !prim_ids)) return c->fail(RT_ERR_ARG, "bad prim_ids");
@@ -610,6 +626,7 @@ int rt_set_shard(rt_ctx* c, int32_t rank, int32_t world) {
     if (!c) return RT_ERR_ARG;
     if (world < 1 || rank < 0 || rank >= world) return c->fail(RT_ERR_ARG, "rank %d of world %d", rank, world);
     c->rank = rank; c->world = world;
+    c->drop_graphs();
     if (c->have_scene) {
         RT_HIP(c, hipSetDevice(c->device));
         RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -818,6 +835,37 @@ static int finish_stats(rt_ctx* c, rt_stats* st, double ms, StageTimer* tm) {
 int rt_render_device(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev, rt_stats* stats) {
     if (!c || !cfg || !rgb_out_dev) return RT_ERR_ARG;
     auto t0 = std::chrono::steady_clock::now();
+    const long long spp = (long long)(cfg->anti_aliasing ? cfg->aa_samples : 1) * (cfg->dof ? cfg->dof_samples : 1) *
+                          (cfg->motion_blur ? cfg->mb_samples : 1);
+    if (!stats && c->use_graphs && spp >= 1 && spp <= 64) {
+        rt_ctx::FrameGraph* g = nullptr;
+        for (auto& e : c->graphs)
+            if (e.out == rgb_out_dev && e.stream == c->stream && e.generation == c->generation && std::memcmp(&e.cfg, cfg, sizeof *cfg) == 0) { g = &e; break; }
+        if (g && g->exec) { RT_HIP(c, hipSetDevice(c->device)); RT_HIP(c, hipGraphLaunch(g->exec, c->stream)); return RT_OK; }
+        if (g && g->warm) {
+            // second request: every buffer exists, so recording the frame allocates and synchronises nothing
+            RT_HIP(c, hipSetDevice(c->device));
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                int rc = enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true, nullptr);
+                hipError_t e = hipStreamEndCapture(c->stream, &graph);
+                if (rc == RT_OK && e == hipSuccess && graph && c->last_batches <= 64 &&
+                    hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    (void)hipGraphDestroy(graph);
+                    RT_HIP(c, hipGraphLaunch(g->exec, c->stream));
+                    return RT_OK;
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+                g->exec = nullptr; g->warm = false;          // not capturable (or too long): plain launches from now on
+                (void)hipGetLastError();
+                if (rc != RT_OK) return rc;
+            } else (void)hipGetLastError();
+        } else if (!g) {
+            if (c->graphs.size() >= 8) { if (c->graphs.front().exec) (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
+            rt_ctx::FrameGraph e{}; e.cfg = *cfg; e.out = rgb_out_dev; e.stream = c->stream; e.generation = c->generation; e.warm = true; e.exec = nullptr;
+            c->graphs.push_back(e);
+        }
+    }
     StageTimer tm; tm.on = stats != nullptr; tm.pool = &c->event_pool;
     int rc = enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true, &tm);
     if (rc != RT_OK) { double sm[ST_COUNT]; (void)hipStreamSynchronize(c->stream); tm.collect(sm); return rc; }

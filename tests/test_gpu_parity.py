@@ -238,3 +238,26 @@ def test_scene_blob_round_trip_renders_identically(textures_dir):
     for s in (ls, ps):
         r = api.Renderer(0); r.upload(s); imgs.append(r.render(cfg)[0]); r.close()
     assert np.array_equal(imgs[0], imgs[1]) and imgs[0].max() > 0
+
+
+def test_graph_replay_equals_plain_launches():
+    """rt_render_device records a frame's launch sequence on its second call and replays it from the third on;
+    the replayed frames must be the frame rt_render produces, also after the scene changes."""
+    flags = ["-rd", "3", "-grs", "1", "-ss", "-sss", "4"]
+    cfg, _ = api.parse_args(flags)
+    r = api.Renderer(0)
+    for scene in ("ref", "glass"):
+        ls = api.LoadedScene(cases.SCENES[scene](), cfg)
+        r.upload(ls)
+        want, _ = r.render(cfg)
+        out = torch.zeros(r.out_bytes(), dtype=torch.uint8, device="cuda")
+        for k in range(5):
+            out.zero_()
+            r.render_device(cfg, out.data_ptr()); r.synchronize()
+            got = out.cpu().numpy().reshape(want.shape)
+            assert np.array_equal(got, want), f"{scene}: call {k} differs"
+        ls.close()
+    r.set_option("graphs", 0)
+    out.zero_(); r.render_device(cfg, out.data_ptr()); r.synchronize()
+    assert np.array_equal(out.cpu().numpy().reshape(want.shape), want)
+    r.close()
