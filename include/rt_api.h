@@ -185,7 +185,9 @@ int rt_set_stream(rt_ctx* ctx, void* hip_stream);
  * depth-8 tree, or the whole scene for -u) are searched through a second-level hierarchy instead of one by
  * one; default 8, a huge value turns the hierarchy off.  "graphs" = 0/1: whether rt_render_device (without
  * statistics) records a frame's launch sequence into a HIP graph on its second call with the same configuration,
- * output pointer and stream, and replays it afterwards; default 1. */
+ * output pointer and stream, and replays it afterwards; default 1.  "overlap" = 0/1: whether frames rendered
+ * without statistics trace the shadow rays of the primary hits on a second, internal stream while the render
+ * stream traces the deeper recursion levels (joined before shading; the caller sees one stream); default 1. */
 int rt_set_option(rt_ctx* ctx, const char* name, int64_t value);
 
 /* Copies the scene to the device (replaces raytracer.cpp:55-59 as the producer of the render loop's inputs). */

@@ -218,6 +218,11 @@ struct rt_ctx {
     std::vector<FrameGraph> graphs;
     unsigned long long generation = 0;
     int use_graphs = 1;
+    // Second stream on which the shadow rays of the primary hits run while the render stream traces the deeper
+    // recursion levels (fork and join through the two events; works the same under graph capture).
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int overlap = 1;
     void drop_graphs() {
         for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
         graphs.clear(); ++generation;
@@ -265,6 +270,10 @@ rt_ctx* rt_create(int device_id, uint64_t workspace_bytes) {
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return nullptr; }
     c->stream = c->own_stream;
+    e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); rt_destroy(c); return nullptr; }
     return c;
 }
 
@@ -272,6 +281,9 @@ void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     DevBuf<float4>* f4s[] = { &c->d_nodes, &c->d_mats, &c->d_plane_uv, &c->d_texels, &c->d_lights, &c->d_verts, &c->d_file_planes,
                               &c->d_file_cubes, &c->d_file_spheres, &c->d_leaf_planes, &c->d_leaf_cubes, &c->d_leaf_spheres,
                               &c->q_a[0], &c->q_a[1], &c->q_b[0], &c->q_b[1], &c->n_a, &c->n_b, &c->n_c, &c->n_col, &c->accum };
@@ -300,6 +312,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
         return RT_OK;
     }
     if (std::strcmp(name, "graphs") == 0) { c->use_graphs = value != 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "overlap") == 0) { c->overlap = value != 0; c->drop_graphs(); return RT_OK; }
     return c->fail(RT_ERR_ARG, "unknown option %s", name);
 }
 
@@ -775,7 +788,9 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     tm->s = s;
     const unsigned long long n_batches = (unsigned long long)((n_slots + B - 1) / B) * (unsigned long long)S;
     if (n_batches > 64) tm->on = false;
-    tm->reserve((size_t)n_batches * (size_t)(2 * D + 3) * 2 + 2);
+    tm->reserve((size_t)n_batches * (size_t)(2 * D + 4) * 2 + 2);
+    const bool split = L > 0 && D >= 1 && k > 0;                 // shadow rays in two launches: level 0, then the rest
+    const bool overlap = split && c->overlap && !tm->on;         // stage times are only meaningful on one stream
     for (long long begin = 0; begin < n_slots; begin += B) {
         const int count = (int)std::min<long long>(B, n_slots - begin);
         f.pix_begin = (int)begin; f.pix_count = count;
@@ -783,13 +798,21 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         for (int smp = 0; smp < S; ++smp) {
             f.sample = smp;
             RT_HIP(c, hipMemsetAsync(c->ctr.p, 0, RT_C_TOTAL * sizeof(int), s));   // counters and level starts of the batch
+            if (!grouped) RT_HIP(c, hipMemsetAsync(c->shadow.p, 0, cap_nodes * (size_t)std::max(L, 1) * sizeof(float), s));
             for (int level = 0; level <= D; ++level) {
                 tm->begin(level == 0 ? ST_EXTEND_PRIMARY : ST_EXTEND_SECONDARY);
                 rt_launch_extend(s, c->scene, f, w, level, level == 0 ? grid0 : max_grid);
                 tm->end();
+                if (level == 0 && split) {
+                    // the primary hits are final: their shadow rays start now, beside the deeper levels' tracing
+                    hipStream_t ss = overlap ? c->aux_stream : s;
+                    if (overlap) { RT_HIP(c, hipEventRecord(c->ev_fork, s)); RT_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0)); }
+                    tm->begin(ST_SHADOW); rt_launch_shadow(ss, c->scene, f, w, 0, 0, max_grid); tm->end();
+                    if (overlap) RT_HIP(c, hipEventRecord(c->ev_join, c->aux_stream));
+                }
             }
-            if (!grouped) RT_HIP(c, hipMemsetAsync(c->shadow.p, 0, cap_nodes * (size_t)std::max(L, 1) * sizeof(float), s));
-            if (L > 0) { tm->begin(ST_SHADOW); rt_launch_shadow(s, c->scene, f, w, max_grid); tm->end(); }
+            if (L > 0) { tm->begin(ST_SHADOW); rt_launch_shadow(s, c->scene, f, w, split ? 1 : 0, D, max_grid); tm->end(); }
+            if (overlap) RT_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
             for (int level = D; level >= 0; --level) {
                 tm->begin(ST_SHADE);
                 rt_launch_shade(s, c->scene, f, w, level, level == 0 ? grid0 : max_grid);

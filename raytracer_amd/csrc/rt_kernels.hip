@@ -751,7 +751,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) void k_extend(DevScene s
 // when the reported hit is nearer than the sampled point.  Output = number of unblocked samples per (hit, light).
 // ---------------------------------------------------------------------------------------------------------
 template <bool SUB>
-__global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene sc, DevFrame f, DevWork w) {
+__global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene sc, DevFrame f, DevWork w, int lv_begin, int lv_end) {
     extern __shared__ float4 s_mem[];
     float4* s_nodes = s_mem;
     int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
@@ -762,6 +762,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene s
         int acc = 0;
         for (int lv = 0; lv <= f.max_depth; ++lv) {
             s_first[lv] = acc;
+            if (lv < lv_begin || lv > lv_end) continue;                 // this launch covers levels lv_begin..lv_end only
             acc += min(w.ctr[RT_C_NODE_CNT + lv], w.node_off[lv + 1] - w.node_off[lv]);
         }
         s_first[f.max_depth + 1] = acc;
@@ -1006,9 +1007,9 @@ void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, cons
     }
 }
 
-void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid) {
-    if (sc.sub_nodes) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w);
-    else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w);
+void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid) {
+    if (sc.sub_nodes) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w, lv_begin, lv_end);
+    else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w, lv_begin, lv_end);
 }
 
 void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {

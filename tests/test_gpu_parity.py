@@ -261,3 +261,28 @@ def test_graph_replay_equals_plain_launches():
     out.zero_(); r.render_device(cfg, out.data_ptr()); r.synchronize()
     assert np.array_equal(out.cpu().numpy().reshape(want.shape), want)
     r.close()
+
+
+def test_shadow_overlap_equals_serial_launches():
+    """Without statistics the shadow rays of the primary hits run on a second stream beside the deeper levels'
+    tracing; with many batches per frame (small workspace, several samples) the forked frames must equal the
+    single-stream ones bit for bit, with and without graph replay."""
+    flags = ["-rd", "3", "-grs", "1", "-ss", "-sss", "4", "-aa", "-aas", "3", "-dof", "-dofs", "2"]
+    cfg, _ = api.parse_args(flags)
+    ls = api.LoadedScene(cases.SCENES["glass"](), cfg)
+    imgs = {}
+    for overlap in (0, 1):
+        for graphs in (0, 1):
+            r = api.Renderer(0, workspace_bytes=24 << 20)
+            r.set_option("overlap", overlap); r.set_option("graphs", graphs)
+            r.upload(ls)
+            out = torch.zeros(r.out_bytes(), dtype=torch.uint8, device="cuda")
+            for _ in range(3):
+                out.zero_(); r.render_device(cfg, out.data_ptr()); r.synchronize()
+            imgs[(overlap, graphs)] = out.cpu().numpy().copy()
+            r.close()
+    ls.close()
+    base = imgs[(0, 0)]
+    assert base.max() > 0
+    for key, img in imgs.items():
+        assert np.array_equal(img, base), f"overlap, graphs = {key} differs from the serial frame"
