@@ -1,0 +1,39 @@
+// On-device construction of the second-level hierarchies (rt_build.hip) and of the leaf-order primitive arrays.
+#ifndef RT_BUILD_H
+#define RT_BUILD_H
+
+#include "rt_types.h"
+
+// One group of primitives that gets a hierarchy: class-wise ranges in a primitive set, and where its items,
+// entries and nodes go.  A group of n items becomes a perfect binary tree with 2^depth runs of 2..RT_SUB_LEAF
+// entries (depth = ceil(log2(ceil(n / RT_SUB_LEAF))) >= 1), i.e. 2^depth - 1 nodes starting at node_base.
+struct BuildGroup {
+    int p0, pn, c0, cn, s0, sn;
+    int item_base;     // first item of the group = first entry of the group, relative to the build's entry_base
+    int node_base;     // absolute index of the group's root in the node array
+    int n, depth;
+};
+
+inline int rt_build_depth(long long n) {
+    long long runs = (n + RT_SUB_LEAF - 1) / RT_SUB_LEAF; int d = 0;
+    while ((1ll << d) < runs) ++d;
+    return d < 1 ? 1 : d;
+}
+
+// Union of the true bounds of every primitive of `set` (no sphere enlargement): out6 = min xyz, max xyz.
+hipError_t rt_build_scene_bounds(hipStream_t s, const DevPrimSet& set, float out6[6]);
+
+// Builds the hierarchies of `groups` (host array, items numbered group after group) over `set`.
+// sphere_e = squared-distance rounding allowance of the sphere test; nodes / entries = device arrays (absolute node
+// indices; entries start at entry_base).  When final6 != NULL it receives the union of the (enlarged) item boxes.
+// Synchronises the stream.
+hipError_t rt_build_hierarchies(hipStream_t s, const DevPrimSet& set, const BuildGroup* groups, int n_groups, long long n_items,
+                                double sphere_e, float4* nodes, int* entries, long long entry_base, float final6[6]);
+
+// Leaf-order copies of the file-order primitive records.  leaf_desc (host): per leaf (first id in prim_ids, planes,
+// cubes, spheres) and (first leaf-order plane, cube, sphere, 0).  prim_ids_dev holds validated indices.
+struct LeafGather { int first_id, n_planes, n_cubes, n_spheres, lp0, lc0, ls0, pad; };
+hipError_t rt_build_gather_leaves(hipStream_t s, const DevPrimSet& fileset, const int* prim_ids_dev, const LeafGather* leaves, int n_leaves,
+                                  float4* leaf_planes, float4* leaf_cubes, float4* leaf_spheres);
+
+#endif

@@ -1,0 +1,384 @@
+// On-device construction of the second-level hierarchies.
+//
+// The reference's tree stops at depth 8 (bvh.cpp:109-117), so every leaf of a large scene - and the whole scene for
+// -u (raytracer.cpp:202-256) - is a long list that the traversal kernels search through a binary hierarchy of their
+// own.  Building those hierarchies is sort-shaped, HBM-bound work:
+//   1. one lane per primitive: true bounds (everything the primitive can occupy for ray times in [0,1], enlarged for
+//      rounding and for what the reference's float sphere test reports outside the geometry);
+//   2. every group becomes a perfect binary tree over an ordering of its items: node j of level l owns the items at
+//      positions [j*n >> l, (j+1)*n >> l), the 2^depth runs at the bottom hold 2..4 items.  The ordering is made level
+//      by level, top down: the centres of each node's items are bounded (atomics per node), and one radix sort over
+//      all items of all groups (rocPRIM; key = node << 32 | centre along the node's widest axis) puts the lower half
+//      of every node first - a median split of every node of the level at once;
+//   3. bottom up: the lowest interior level unions item boxes, each level above the two boxes stored in its children.
+// The tree shape is fixed by the item count alone, so its depth is known before anything is built
+// (<= 22 for 16M primitives; the traversal stack holds RT_SUB_STACK entries).
+// Nothing here influences a rendered value: the hierarchy only decides which primitives a ray may skip.
+#include "rt_build.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+#define DEVI __device__ __forceinline__
+
+DEVI int f2i(float f) { return __float_as_int(f); }
+DEVI float i2f(int i) { return __int_as_float(i); }
+
+// floats as unsigned integers that order the same way (for atomicMin / atomicMax)
+DEVI unsigned enc_ordered(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+inline float dec_ordered(unsigned u) { u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; std::memcpy(&f, &u, 4); return f; }
+
+struct DBox { float mn[3], mx[3]; };
+DEVI void db_clear(DBox& b) { for (int i = 0; i < 3; ++i) { b.mn[i] = INFINITY; b.mx[i] = -INFINITY; } }
+// NaN coordinates are ignored, exactly like std::min / std::max with the accumulator first
+DEVI void db_add(DBox& b, float x, float y, float z) {
+    b.mn[0] = (x < b.mn[0]) ? x : b.mn[0]; b.mx[0] = (b.mx[0] < x) ? x : b.mx[0];
+    b.mn[1] = (y < b.mn[1]) ? y : b.mn[1]; b.mx[1] = (b.mx[1] < y) ? y : b.mx[1];
+    b.mn[2] = (z < b.mn[2]) ? z : b.mn[2]; b.mx[2] = (b.mx[2] < z) ? z : b.mx[2];
+}
+DEVI void db_grow(DBox& b) {
+    for (int i = 0; i < 3; ++i) {
+        float m = fabsf(b.mn[i]), M = fabsf(b.mx[i]), w = b.mx[i] - b.mn[i];
+        float big = (m < M) ? M : m; big = (big < w) ? w : big;
+        float e = 1e-5f * big + 1e-6f;
+        b.mn[i] -= e; b.mx[i] += e;
+    }
+}
+
+// True bounds of item k of a group (planes, then cubes, then spheres); returns the packed entry.
+DEVI unsigned item_box(const DevPrimSet& S, const BuildGroup& g, int k, double sphere_e, DBox& b) {
+    db_clear(b);
+    if (k < g.pn) {
+        const int idx = g.p0 + k;
+        const float4 w0 = S.planes[3 * (size_t)idx], w1 = S.planes[3 * (size_t)idx + 1];
+        const int first = f2i(w0.w), nv = f2i(w1.w) & 0xffff;
+        for (int v = 0; v < nv; ++v) { float4 p = S.verts[first + v]; db_add(b, p.x, p.y, p.z); }
+        db_grow(b);
+        return (unsigned)idx;
+    }
+    k -= g.pn;
+    if (k < g.cn) {
+        const int idx = g.c0 + k;
+        const float4* q = S.cubes + 6 * (size_t)idx;
+        const float4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+        const float cx = w2.x, sx = w2.y, cy = w2.z, sy = w2.w, cz = w3.x, sz = w3.y, scale = w0.w;
+        for (int m = 0; m < 8; ++m) {
+            float x = (m & 1) ? 1.0f : -1.0f, y = (m & 2) ? 1.0f : -1.0f, z = (m & 4) ? 1.0f : -1.0f;
+            float y1 = y * cx - z * sx, z1 = y * sx + z * cx;
+            float x2 = x * cy + z1 * sy, z2 = -x * sy + z1 * cy;
+            float rx = (x2 * cz - y1 * sz) * scale, ry = (x2 * sz + y1 * cz) * scale, rz = z2 * scale;
+            db_add(b, rx + w0.x, ry + w0.y, rz + w0.z);
+            db_add(b, rx + w1.x, ry + w1.y, rz + w1.z);
+        }
+        db_grow(b);
+        return (1u << 30) | (unsigned)idx;
+    }
+    k -= g.cn;
+    const int idx = g.s0 + k;
+    const float4 w0 = S.spheres[2 * (size_t)idx], w1 = S.spheres[2 * (size_t)idx + 1];
+    const float r = fabsf(w0.w);
+    db_add(b, w0.x - r, w0.y - r, w0.z - r); db_add(b, w0.x + r, w0.y + r, w0.z + r);
+    db_add(b, w1.x - r, w1.y - r, w1.z - r); db_add(b, w1.x + r, w1.y + r, w1.z + r);
+    db_grow(b);
+    if (sphere_e > 0.0) {
+        // sphere.cpp:131-139 forms |l|^2 - tca^2 in float: a reported hit lies within sqrt(r^2 + e) of the centre
+        const double rd = (double)r;
+        const float extra = (float)(sqrt(rd * rd + sphere_e) - rd) * 1.01f;
+        if (extra < INFINITY) for (int i = 0; i < 3; ++i) { b.mn[i] -= extra; b.mx[i] += extra; }
+    }
+    return (2u << 30) | (unsigned)idx;
+}
+
+DEVI float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) { float t = __shfl_xor(v, o); v = (t < v) ? t : v; } return v; }
+DEVI float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) { float t = __shfl_xor(v, o); v = (v < t) ? t : v; } return v; }
+
+// blockIdx.y = group.  BOXES: write boxes (mn.w = entry bits) and the initial ordering; REDUCE: union into `red`.
+template <bool BOXES, bool REDUCE>
+__global__ __launch_bounds__(256) void k_items(DevPrimSet S, const BuildGroup* __restrict__ groups, double sphere_e,
+                                               float4* __restrict__ boxes, unsigned* __restrict__ order, unsigned* __restrict__ red) {
+    const BuildGroup g = groups[blockIdx.y];
+    if ((long long)blockIdx.x * blockDim.x >= g.n) return;   // whole workgroup idle (groups differ in size)
+    DBox acc; db_clear(acc);
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < g.n; k += (long long)gridDim.x * blockDim.x) {
+        DBox b;
+        const unsigned entry = item_box(S, g, (int)k, sphere_e, b);
+        if (BOXES) {
+            const size_t item = (size_t)g.item_base + (size_t)k;
+            boxes[2 * item] = make_float4(b.mn[0], b.mn[1], b.mn[2], i2f((int)entry));
+            boxes[2 * item + 1] = make_float4(b.mx[0], b.mx[1], b.mx[2], 0.0f);
+            order[item] = (unsigned)item;
+        }
+        if (REDUCE) { db_add(acc, b.mn[0], b.mn[1], b.mn[2]); db_add(acc, b.mx[0], b.mx[1], b.mx[2]); }
+    }
+    if (REDUCE) {
+        for (int i = 0; i < 3; ++i) {
+            float lo = wave_min(acc.mn[i]), hi = wave_max(acc.mx[i]);
+            if ((threadIdx.x & 63) == 0) { atomicMin(&red[i], enc_ordered(lo)); atomicMax(&red[3 + i], enc_ordered(hi)); }
+        }
+    }
+}
+
+// Node (of level `level`) that owns position p of a group of n items: ranges are [j*n >> level, (j+1)*n >> level).
+DEVI unsigned node_of(long long p, int n, int level) {
+    return (unsigned)((((unsigned long long)(p + 1) << level) + (unsigned long long)n - 1ull) / (unsigned long long)n - 1ull);
+}
+
+__global__ __launch_bounds__(256) void k_fill_bounds(unsigned* __restrict__ segb, long long n_nodes) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes * 6; i += (long long)gridDim.x * blockDim.x)
+        segb[i] = (i % 6 < 3) ? 0xffffffffu : 0u;
+}
+
+// Bounds of the item centres of every node of `level` (groups that are still being split).
+__global__ __launch_bounds__(256) void k_node_bounds(const BuildGroup* __restrict__ groups, const unsigned* __restrict__ node_base, int level,
+                                                     const float4* __restrict__ boxes, const unsigned* __restrict__ order, unsigned* __restrict__ segb) {
+    const BuildGroup g = groups[blockIdx.y];
+    if (g.depth <= level) return;
+    const unsigned base = node_base[blockIdx.y];
+    for (long long p0 = (long long)blockIdx.x * blockDim.x; p0 < g.n; p0 += (long long)gridDim.x * blockDim.x) {
+        const long long p = p0 + threadIdx.x;
+        const bool active = p < g.n;
+        unsigned node = 0xffffffffu;
+        float c[3] = { 0.0f, 0.0f, 0.0f };
+        if (active) {
+            const size_t item = order[(size_t)g.item_base + (size_t)p];
+            const float4 mn = boxes[2 * item], mx = boxes[2 * item + 1];
+            c[0] = 0.5f * (mn.x + mx.x); c[1] = 0.5f * (mn.y + mx.y); c[2] = 0.5f * (mn.z + mx.z);
+            node = base + node_of(p, g.n, level);
+        }
+        // a wavefront that lies inside one node (the usual case near the top) reduces first and issues six atomics
+        const unsigned long long act = __ballot(active);
+        if (act == 0ull) continue;
+        const unsigned first = __shfl(node, __ffsll((long long)act) - 1);
+        const bool uniform = __ballot(active && node == first) == act;
+        if (uniform) {
+            for (int i = 0; i < 3; ++i) {
+                const bool ok = active && c[i] == c[i];
+                float lo = wave_min(ok ? c[i] : INFINITY), hi = wave_max(ok ? c[i] : -INFINITY);
+                if ((threadIdx.x & 63) == 0) { atomicMin(&segb[6 * (size_t)first + i], enc_ordered(lo)); atomicMax(&segb[6 * (size_t)first + 3 + i], enc_ordered(hi)); }
+            }
+        } else if (active) {
+            for (int i = 0; i < 3; ++i)
+                if (c[i] == c[i]) { atomicMin(&segb[6 * (size_t)node + i], enc_ordered(c[i])); atomicMax(&segb[6 * (size_t)node + 3 + i], enc_ordered(c[i])); }
+        }
+    }
+}
+
+DEVI float dec_ordered_dev(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+// Sort key of every position: node << 32 | centre along the node's widest axis.  Items of a group that is already
+// split down to its runs keep their run (key = run, equal low bits; the sort is stable).
+__global__ __launch_bounds__(256) void k_node_keys(const BuildGroup* __restrict__ groups, const unsigned* __restrict__ node_base, int level,
+                                                   const float4* __restrict__ boxes, const unsigned* __restrict__ order, const unsigned* __restrict__ segb,
+                                                   unsigned long long* __restrict__ keys) {
+    const BuildGroup g = groups[blockIdx.y];
+    const unsigned base = node_base[blockIdx.y];
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < g.n; p += (long long)gridDim.x * blockDim.x) {
+        const size_t pos = (size_t)g.item_base + (size_t)p;
+        if (g.depth <= level) { keys[pos] = (unsigned long long)(base + node_of(p, g.n, g.depth)) << 32; continue; }
+        const unsigned node = base + node_of(p, g.n, level);
+        const unsigned* sb = segb + 6 * (size_t)node;
+        const float e0 = dec_ordered_dev(sb[3]) - dec_ordered_dev(sb[0]), e1 = dec_ordered_dev(sb[4]) - dec_ordered_dev(sb[1]),
+                    e2 = dec_ordered_dev(sb[5]) - dec_ordered_dev(sb[2]);
+        int axis = 0; float ext = e0;
+        if (e1 > ext) { axis = 1; ext = e1; }
+        if (e2 > ext) axis = 2;
+        const size_t item = order[pos];
+        const float4 mn = boxes[2 * item], mx = boxes[2 * item + 1];
+        const float cv = axis == 0 ? 0.5f * (mn.x + mx.x) : (axis == 1 ? 0.5f * (mn.y + mx.y) : 0.5f * (mn.z + mx.z));
+        keys[pos] = ((unsigned long long)node << 32) | (unsigned long long)enc_ordered(cv);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_entries(const float4* __restrict__ boxes, const unsigned* __restrict__ sorted, long long n,
+                                                 int* __restrict__ entries) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        entries[i] = f2i(boxes[2 * (size_t)sorted[i]].w);
+}
+
+DEVI void box_union(float4& mn, float4& mx, float4 a, float4 b) {
+    mn.x = fminf(mn.x, a.x); mn.y = fminf(mn.y, a.y); mn.z = fminf(mn.z, a.z);
+    mx.x = fmaxf(mx.x, b.x); mx.y = fmaxf(mx.y, b.y); mx.z = fmaxf(mx.z, b.z);
+}
+
+// Lowest interior level: node = parent of two runs of sorted items.
+__global__ __launch_bounds__(256) void k_leaf_parents(const BuildGroup* __restrict__ groups, const float4* __restrict__ boxes,
+                                                      const unsigned* __restrict__ sorted, long long entry_base, float4* __restrict__ nodes) {
+    const BuildGroup g = groups[blockIdx.y];
+    const long long half = 1ll << (g.depth - 1);
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < half; t += (long long)gridDim.x * blockDim.x) {
+        float4 out[4];
+        for (int side = 0; side < 2; ++side) {
+            const long long j = 2 * t + side;
+            const long long a = (j * (long long)g.n) >> g.depth, b = ((j + 1) * (long long)g.n) >> g.depth;
+            float4 mn = make_float4(INFINITY, INFINITY, INFINITY, 0.0f), mx = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+            for (long long p = a; p < b; ++p) {
+                const size_t item = sorted[(size_t)g.item_base + (size_t)p];
+                box_union(mn, mx, boxes[2 * item], boxes[2 * item + 1]);
+            }
+            mn.w = i2f(~(int)(entry_base + g.item_base + a));
+            mx.w = i2f((int)(b - a));
+            out[2 * side] = mn; out[2 * side + 1] = mx;
+        }
+        float4* nd = nodes + 4 * ((size_t)g.node_base + (size_t)(half - 1 + t));
+        nd[0] = out[0]; nd[1] = out[1]; nd[2] = out[2]; nd[3] = out[3];
+    }
+}
+
+// Level `depth - height` of every group that is at least `height` levels deep (height >= 2): union of the children.
+__global__ __launch_bounds__(256) void k_upper_level(const BuildGroup* __restrict__ groups, int height, float4* __restrict__ nodes) {
+    const BuildGroup g = groups[blockIdx.y];
+    if (g.depth < height) return;
+    const long long width = 1ll << (g.depth - height);
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < width; t += (long long)gridDim.x * blockDim.x) {
+        const long long i = width - 1 + t;
+        float4 out[4];
+        for (int side = 0; side < 2; ++side) {
+            const long long ch = 2 * i + 1 + side;
+            const float4* cd = nodes + 4 * ((size_t)g.node_base + (size_t)ch);
+            float4 mn = cd[0], mx = cd[1];
+            box_union(mn, mx, cd[2], cd[3]);
+            mn.w = i2f(g.node_base + (int)ch); mx.w = i2f(0);
+            out[2 * side] = mn; out[2 * side + 1] = mx;
+        }
+        float4* nd = nodes + 4 * ((size_t)g.node_base + (size_t)i);
+        nd[0] = out[0]; nd[1] = out[1]; nd[2] = out[2]; nd[3] = out[3];
+    }
+}
+
+// blockIdx.y = leaf: copy the leaf's primitive records from the file-order arrays.  A leaf's planes take their
+// offset vertex from the file-order first vertex (kept in the spare lanes of the file record's third word).
+__global__ __launch_bounds__(256) void k_gather_leaves(DevPrimSet F, const int* __restrict__ ids, const LeafGather* __restrict__ leaves,
+                                                       float4* __restrict__ lp, float4* __restrict__ lc, float4* __restrict__ ls) {
+    const LeafGather L = leaves[blockIdx.y];
+    const int n = L.n_planes + L.n_cubes + L.n_spheres;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const int id = ids[L.first_id + k];
+        if (k < L.n_planes) {
+            const float4 w0 = F.planes[3 * (size_t)id], w1 = F.planes[3 * (size_t)id + 1], w2 = F.planes[3 * (size_t)id + 2];
+            float4* o = lp + 3 * ((size_t)L.lp0 + (size_t)k);
+            o[0] = w0; o[1] = make_float4(w2.y, w2.z, w2.w, w1.w); o[2] = make_float4(w2.x, 0.0f, 0.0f, 0.0f);
+        } else if (k < L.n_planes + L.n_cubes) {
+            const float4* q = F.cubes + 6 * (size_t)id;
+            float4* o = lc + 6 * ((size_t)L.lc0 + (size_t)(k - L.n_planes));
+            for (int w = 0; w < 6; ++w) o[w] = q[w];
+        } else {
+            float4* o = ls + 2 * ((size_t)L.ls0 + (size_t)(k - L.n_planes - L.n_cubes));
+            o[0] = F.spheres[2 * (size_t)id]; o[1] = F.spheres[2 * (size_t)id + 1];
+        }
+    }
+}
+
+struct Scratch {                       // device allocations of one build, freed on every path out
+    std::vector<void*> ptrs;
+    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T> hipError_t get(T** out, size_t count) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) { ptrs.push_back(p); *out = (T*)p; }
+        return e;
+    }
+};
+
+#define BUILD_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return e__; } while (0)
+
+inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+const unsigned RED_INIT[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+
+} // namespace
+
+hipError_t rt_build_scene_bounds(hipStream_t s, const DevPrimSet& set, float out6[6]) {
+    const long long n = (long long)set.n_planes + set.n_cubes + set.n_spheres;
+    for (int i = 0; i < 3; ++i) { out6[i] = INFINITY; out6[3 + i] = -INFINITY; }
+    if (n == 0) return hipSuccess;
+    Scratch sc; BuildGroup* d_group; unsigned* d_red;
+    BUILD_TRY(sc.get(&d_group, 1)); BUILD_TRY(sc.get(&d_red, 6));
+    BuildGroup g{}; g.pn = set.n_planes; g.cn = set.n_cubes; g.sn = set.n_spheres; g.n = (int)n; g.depth = 1;
+    BUILD_TRY(hipMemcpyAsync(d_group, &g, sizeof g, hipMemcpyHostToDevice, s));
+    BUILD_TRY(hipMemcpyAsync(d_red, RED_INIT, sizeof RED_INIT, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL((k_items<false, true>), dim3(grid_for(n), 1), dim3(256), 0, s, set, d_group, 0.0, (float4*)nullptr, (unsigned*)nullptr, d_red);
+    BUILD_TRY(hipGetLastError());
+    unsigned red[6];
+    BUILD_TRY(hipMemcpyAsync(red, d_red, sizeof red, hipMemcpyDeviceToHost, s));
+    BUILD_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < 6; ++i) out6[i] = dec_ordered(red[i]);
+    return hipSuccess;
+}
+
+hipError_t rt_build_hierarchies(hipStream_t s, const DevPrimSet& set, const BuildGroup* groups, int n_groups, long long n_items,
+                                double sphere_e, float4* nodes, int* entries, long long entry_base, float final6[6]) {
+    if (final6) for (int i = 0; i < 3; ++i) { final6[i] = INFINITY; final6[3 + i] = -INFINITY; }
+    if (n_groups <= 0 || n_items <= 0) return hipSuccess;
+    if (n_groups > 65535 || n_items > 0x7fffffffll) return hipErrorInvalidValue;
+    int max_n = 0, max_depth = 1;
+    for (int g = 0; g < n_groups; ++g) { max_n = groups[g].n > max_n ? groups[g].n : max_n; max_depth = groups[g].depth > max_depth ? groups[g].depth : max_depth; }
+    // first node of every group at every level (a group that is already down to its runs keeps 2^depth of them)
+    std::vector<unsigned> node_base((size_t)(max_depth + 1) * (size_t)n_groups);
+    std::vector<long long> level_nodes((size_t)max_depth + 1, 0);
+    for (int l = 0; l <= max_depth; ++l) {
+        long long acc = 0;
+        for (int g = 0; g < n_groups; ++g) { node_base[(size_t)l * n_groups + g] = (unsigned)acc; acc += 1ll << (l < groups[g].depth ? l : groups[g].depth); }
+        level_nodes[(size_t)l] = acc;
+        if (acc > 0xffffffffll) return hipErrorInvalidValue;
+    }
+    Scratch sc;
+    BuildGroup* d_groups; unsigned *d_red, *d_node_base, *d_segb; float4* d_boxes; unsigned long long *d_keys, *d_keys2; unsigned *d_ord, *d_ord2;
+    BUILD_TRY(sc.get(&d_groups, (size_t)n_groups)); BUILD_TRY(sc.get(&d_red, 6));
+    BUILD_TRY(sc.get(&d_node_base, node_base.size()));
+    BUILD_TRY(sc.get(&d_segb, 6 * (size_t)level_nodes[(size_t)max_depth - 1]));
+    BUILD_TRY(sc.get(&d_boxes, 2 * (size_t)n_items));
+    BUILD_TRY(sc.get(&d_keys, (size_t)n_items)); BUILD_TRY(sc.get(&d_keys2, (size_t)n_items));
+    BUILD_TRY(sc.get(&d_ord, (size_t)n_items)); BUILD_TRY(sc.get(&d_ord2, (size_t)n_items));
+    BUILD_TRY(hipMemcpyAsync(d_groups, groups, sizeof(BuildGroup) * (size_t)n_groups, hipMemcpyHostToDevice, s));
+    BUILD_TRY(hipMemcpyAsync(d_node_base, node_base.data(), sizeof(unsigned) * node_base.size(), hipMemcpyHostToDevice, s));
+    BUILD_TRY(hipMemcpyAsync(d_red, RED_INIT, sizeof RED_INIT, hipMemcpyHostToDevice, s));
+
+    const int gx = grid_for(max_n);
+    if (final6) hipLaunchKernelGGL((k_items<true, true>), dim3(gx, n_groups), dim3(256), 0, s, set, d_groups, sphere_e, d_boxes, d_ord, d_red);
+    else hipLaunchKernelGGL((k_items<true, false>), dim3(gx, n_groups), dim3(256), 0, s, set, d_groups, sphere_e, d_boxes, d_ord, d_red);
+    BUILD_TRY(hipGetLastError());
+
+    size_t temp_bytes = 0;
+    BUILD_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_ord, d_ord2, (size_t)n_items, 0u, 64u, s));
+    char* d_temp; BUILD_TRY(sc.get(&d_temp, temp_bytes));
+    for (int level = 0; level < max_depth; ++level) {
+        const unsigned* nb = d_node_base + (size_t)level * n_groups;
+        hipLaunchKernelGGL(k_fill_bounds, dim3(grid_for(level_nodes[(size_t)level] * 6)), dim3(256), 0, s, d_segb, level_nodes[(size_t)level]);
+        hipLaunchKernelGGL(k_node_bounds, dim3(gx, n_groups), dim3(256), 0, s, d_groups, nb, level, d_boxes, d_ord, d_segb);
+        hipLaunchKernelGGL(k_node_keys, dim3(gx, n_groups), dim3(256), 0, s, d_groups, nb, level, d_boxes, d_ord, d_segb, d_keys);
+        BUILD_TRY(hipGetLastError());
+        int node_bits = 1; while ((1ll << node_bits) < level_nodes[(size_t)level]) ++node_bits;
+        size_t tb = temp_bytes;
+        BUILD_TRY(rocprim::radix_sort_pairs(d_temp, tb, d_keys, d_keys2, d_ord, d_ord2, (size_t)n_items, 0u, (unsigned)(32 + node_bits), s));
+        unsigned* t = d_ord; d_ord = d_ord2; d_ord2 = t;
+    }
+
+    hipLaunchKernelGGL(k_entries, dim3(grid_for(n_items)), dim3(256), 0, s, d_boxes, d_ord, n_items, entries + entry_base);
+    hipLaunchKernelGGL(k_leaf_parents, dim3(grid_for(((long long)max_n + 3) / 4), n_groups), dim3(256), 0, s, d_groups, d_boxes, d_ord, entry_base, nodes);
+    for (int h = 2; h <= max_depth; ++h)
+        hipLaunchKernelGGL(k_upper_level, dim3(grid_for(1ll << (max_depth - h)), n_groups), dim3(256), 0, s, d_groups, h, nodes);
+    BUILD_TRY(hipGetLastError());
+    unsigned red[6];
+    if (final6) BUILD_TRY(hipMemcpyAsync(red, d_red, sizeof red, hipMemcpyDeviceToHost, s));
+    BUILD_TRY(hipStreamSynchronize(s));
+    if (final6) for (int i = 0; i < 6; ++i) final6[i] = dec_ordered(red[i]);
+    return hipSuccess;
+}
+
+hipError_t rt_build_gather_leaves(hipStream_t s, const DevPrimSet& fileset, const int* prim_ids_dev, const LeafGather* leaves, int n_leaves,
+                                  float4* leaf_planes, float4* leaf_cubes, float4* leaf_spheres) {
+    if (n_leaves <= 0) return hipSuccess;
+    Scratch sc; LeafGather* d_leaves;
+    BUILD_TRY(sc.get(&d_leaves, (size_t)n_leaves));
+    BUILD_TRY(hipMemcpyAsync(d_leaves, leaves, sizeof(LeafGather) * (size_t)n_leaves, hipMemcpyHostToDevice, s));
+    long long max_n = 0;
+    for (int i = 0; i < n_leaves; ++i) { long long n = (long long)leaves[i].n_planes + leaves[i].n_cubes + leaves[i].n_spheres; max_n = n > max_n ? n : max_n; }
+    hipLaunchKernelGGL(k_gather_leaves, dim3(grid_for(max_n), n_leaves), dim3(256), 0, s, fileset, prim_ids_dev, d_leaves, leaf_planes, leaf_cubes, leaf_spheres);
+    BUILD_TRY(hipGetLastError());
+    return hipStreamSynchronize(s);
+}

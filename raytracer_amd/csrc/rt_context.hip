@@ -3,8 +3,11 @@
 #include "rt_api.h"
 #include "rt_types.h"
 #include "camera_basis.h"
+#include "rt_build.h"
+#include "rt_parallel.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -177,8 +180,7 @@ struct rt_ctx {
     // host copy of what the BVH upload needs
     bool have_scene = false, have_bvh = false;
     rt_camera camera{};
-    std::vector<rt_sphere> spheres; std::vector<rt_cube> cubes; std::vector<rt_plane> planes;
-    std::vector<float> plane_verts;          // file order
+    int np = 0, nc = 0, ns = 0;              // planes, cubes, spheres of the uploaded scene
     std::vector<float4> h_verts_sorted;      // device layout, indexed by first_vert + k
     std::vector<float4> h_file_planes, h_file_cubes, h_file_spheres;
     int n_lights = 0;
@@ -188,7 +190,12 @@ struct rt_ctx {
     std::vector<float4> h_sub_nodes_file; std::vector<int> h_sub_entries_file;
     int file_sub_root = -1;
     int sub_min_group = RT_SUB_MIN_GROUP;    // groups above this size get a second-level hierarchy (rt_set_option)
-    DevBuf<float4> d_sub_nodes; DevBuf<int> d_sub_entries;
+    int device_build = 1;                    // hierarchies and leaf-order records are made on the GPU (rt_set_option)
+    bool built_on_device = false;            // what the current scene's upload used
+    long long n_file_nodes = 0, n_file_entries = 0;
+    double sphere_e = 0.0;                   // rounding allowance of the float sphere test, see rt_upload_scene
+    DevBuf<float4> d_sub_nodes_file, d_sub_nodes;   // file-order set alone / file-order set followed by the leaves'
+    DevBuf<int> d_sub_entries_file, d_sub_entries, d_prim_ids;
 
     // device scene
     DevBuf<float4> d_nodes, d_mats, d_plane_uv, d_texels, d_lights, d_verts;
@@ -288,7 +295,7 @@ void rt_destroy(rt_ctx* c) {
                               &c->d_file_cubes, &c->d_file_spheres, &c->d_leaf_planes, &c->d_leaf_cubes, &c->d_leaf_spheres,
                               &c->q_a[0], &c->q_a[1], &c->q_b[0], &c->q_b[1], &c->n_a, &c->n_b, &c->n_c, &c->n_col, &c->accum };
     for (auto* b : f4s) b->release();
-    c->d_sub_nodes.release(); c->d_sub_entries.release();
+    c->d_sub_nodes.release(); c->d_sub_entries.release(); c->d_sub_nodes_file.release(); c->d_sub_entries_file.release(); c->d_prim_ids.release();
     c->d_leaves.release(); c->d_tex_desc.release(); c->d_local_tiles.release(); c->n_uv.release(); c->n_pix.release();
     c->link.release(); c->ctr.release(); c->shadow.release(); c->stats.release(); c->out_tmp.release();
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -311,6 +318,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
         c->sub_min_group = value > 0x7fffffff ? 0x7fffffff : (int)value;
         return RT_OK;
     }
+    if (std::strcmp(name, "device_build") == 0) { c->device_build = value != 0; return RT_OK; }
     if (std::strcmp(name, "graphs") == 0) { c->use_graphs = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "overlap") == 0) { c->overlap = value != 0; c->drop_graphs(); return RT_OK; }
     return c->fail(RT_ERR_ARG, "unknown option %s", name);
@@ -338,81 +346,95 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
     RT_HIP(c, hipStreamSynchronize(c->stream));     // previous frames may still read the old arrays
 
     c->drop_graphs();
+    c->have_scene = false; c->have_bvh = false;
     c->camera = sc->camera;
-    c->spheres.assign(sc->spheres, sc->spheres + sc->n_spheres);
-    c->cubes.assign(sc->cubes, sc->cubes + sc->n_cubes);
-    c->planes.assign(sc->planes, sc->planes + sc->n_planes);
-    c->plane_verts.assign(sc->plane_verts, sc->plane_verts + (size_t)sc->n_plane_verts * 3);
     c->n_lights = sc->n_lights;
-    c->have_bvh = false;
-
     const int np = sc->n_planes, nc = sc->n_cubes, ns = sc->n_spheres;
+    if (np >= (1 << 30) || nc >= (1 << 30) || ns >= (1 << 30) || (long long)np + nc + ns > 0x7fffffffll)
+        return c->fail(RT_ERR_ARG, "too many primitives");
+    c->np = np; c->nc = nc; c->ns = ns;
+    // Groups above sub_min_group primitives get a second-level hierarchy; with "device_build" (default) those are
+    // built on the GPU from the uploaded records, otherwise on the host.
+    const bool on_device = c->device_build && (long long)np + nc + ns > c->sub_min_group;
+    c->built_on_device = on_device;
+
     std::vector<float4> mats((size_t)(np + nc + ns) * 3);
-    c->any_reflective = c->any_transparent = false;
-    auto put_mat = [&](int gid, const rt_material& m) -> int {
-        if (m.tex_id >= sc->n_textures) return RT_ERR_ARG;
+    std::atomic<int> any_refl{ 0 }, any_transp{ 0 }, bad_tex{ -1 }, bad_plane{ -1 };
+    auto put_mat = [&](int gid, const rt_material& m) -> bool {
+        if (m.tex_id >= sc->n_textures) { bad_tex = gid; return false; }
         // raytracer.cpp:374-375: mean specular times 0.5 (the 0.5 is a double literal; the product is exact), clamped
         float refl = (float)((double)((m.specular[0] + m.specular[1] + m.specular[2]) / 3.0f) * 0.5);
         refl = sminh(smaxh(refl, 0.0f), 1.0f);
         mats[(size_t)gid * 3 + 0] = f4(m.diffuse[0], m.diffuse[1], m.diffuse[2], m.shininess);
         mats[(size_t)gid * 3 + 1] = f4(m.specular[0], m.specular[1], m.specular[2], m.transparency);
         mats[(size_t)gid * 3 + 2] = f4(m.ior, as_f(m.tex_id < 0 ? -1 : m.tex_id), refl, 0.0f);
-        if (refl > 0) c->any_reflective = true;
-        if (m.transparency > 0) c->any_transparent = true;
-        return RT_OK;
+        if (refl > 0) any_refl = 1;
+        if (m.transparency > 0) any_transp = 1;
+        return true;
     };
 
     // planes: winding-sorted vertices, projection axis, texture axes
     c->h_verts_sorted.assign((size_t)sc->n_plane_verts, f4(0, 0, 0, 0));
     c->h_file_planes.assign((size_t)np * 3, f4(0, 0, 0, 0));
     std::vector<float4> plane_uv((size_t)np * 3, f4(0, 0, 0, 0));
-    for (int i = 0; i < np; ++i) {
-        const rt_plane& p = sc->planes[i];
-        if (p.n_verts < 3 || p.n_verts > 0xffff || p.first_vert < 0 || p.first_vert + p.n_verts > sc->n_plane_verts)
-            return c->fail(RT_ERR_ARG, "plane %d: vertex range out of bounds", i);
-        const float* v = sc->plane_verts + (size_t)p.first_vert * 3;
-        std::vector<int> ord = winding_order(v, p.n_verts, p.normal);
-        for (int k = 0; k < p.n_verts; ++k)
-            c->h_verts_sorted[(size_t)p.first_vert + k] = f4(v[3 * ord[k]], v[3 * ord[k] + 1], v[3 * ord[k] + 2], 0.0f);
-        const float4 s0 = c->h_verts_sorted[(size_t)p.first_vert];
-        const float4 s1 = c->h_verts_sorted[(size_t)p.first_vert + 1];
-        const float4 sl = c->h_verts_sorted[(size_t)p.first_vert + p.n_verts - 1];
-        int packed = p.n_verts | (drop_axis(p.normal) << 16);
-        // File-order set = the objects in the reference's own vectors, which Plane::intersect sorts in place on
-        // first use (plane.cpp:158), so the plane offset is taken from the first SORTED vertex there.
-        c->h_file_planes[(size_t)i * 3 + 0] = f4(p.normal[0], p.normal[1], p.normal[2], as_f(p.first_vert));
-        c->h_file_planes[(size_t)i * 3 + 1] = f4(s0.x, s0.y, s0.z, as_f(packed));
-        c->h_file_planes[(size_t)i * 3 + 2] = f4(as_f(i), 0, 0, 0);
-        // plane.cpp:164-170
-        float us[3] = { s1.x - s0.x, s1.y - s0.y, s1.z - s0.z }, vs[3] = { sl.x - s0.x, sl.y - s0.y, sl.z - s0.z };
-        float ul = len_ref(us), vl = len_ref(vs);
-        rt_normalise_ref(us); rt_normalise_ref(vs);
-        plane_uv[(size_t)i * 3 + 0] = f4(us[0], us[1], us[2], ul);
-        plane_uv[(size_t)i * 3 + 1] = f4(vs[0], vs[1], vs[2], vl);
-        plane_uv[(size_t)i * 3 + 2] = f4(s0.x, s0.y, s0.z, 0.0f);
-        if (put_mat(i, p.mat) != RT_OK) return c->fail(RT_ERR_ARG, "plane %d: texture id out of range", i);
-    }
+    rt_parallel_for((size_t)np, 2048, [&](size_t lo, size_t hi, int) {
+        for (size_t i = lo; i < hi; ++i) {
+            const rt_plane& p = sc->planes[i];
+            if (p.n_verts < 3 || p.n_verts > 0xffff || p.first_vert < 0 || p.first_vert + p.n_verts > sc->n_plane_verts) { bad_plane = (int)i; continue; }
+            const float* v = sc->plane_verts + (size_t)p.first_vert * 3;
+            std::vector<int> ord = winding_order(v, p.n_verts, p.normal);
+            for (int k = 0; k < p.n_verts; ++k)
+                c->h_verts_sorted[(size_t)p.first_vert + k] = f4(v[3 * ord[k]], v[3 * ord[k] + 1], v[3 * ord[k] + 2], 0.0f);
+            const float4 s0 = c->h_verts_sorted[(size_t)p.first_vert];
+            const float4 s1 = c->h_verts_sorted[(size_t)p.first_vert + 1];
+            const float4 sl = c->h_verts_sorted[(size_t)p.first_vert + p.n_verts - 1];
+            int packed = p.n_verts | (drop_axis(p.normal) << 16);
+            // File-order set = the objects in the reference's own vectors, which Plane::intersect sorts in place on
+            // first use (plane.cpp:158), so the plane offset is taken from the first SORTED vertex there.  Leaves hold
+            // copies made before any ray was traced (bvh.cpp:113, :70): their offset comes from the first vertex in
+            // FILE order, which rides in the spare lanes of the third word until the leaf-order copy is made.
+            c->h_file_planes[i * 3 + 0] = f4(p.normal[0], p.normal[1], p.normal[2], as_f(p.first_vert));
+            c->h_file_planes[i * 3 + 1] = f4(s0.x, s0.y, s0.z, as_f(packed));
+            c->h_file_planes[i * 3 + 2] = f4(as_f((int)i), v[0], v[1], v[2]);
+            // plane.cpp:164-170
+            float us[3] = { s1.x - s0.x, s1.y - s0.y, s1.z - s0.z }, vs[3] = { sl.x - s0.x, sl.y - s0.y, sl.z - s0.z };
+            float ul = len_ref(us), vl = len_ref(vs);
+            rt_normalise_ref(us); rt_normalise_ref(vs);
+            plane_uv[i * 3 + 0] = f4(us[0], us[1], us[2], ul);
+            plane_uv[i * 3 + 1] = f4(vs[0], vs[1], vs[2], vl);
+            plane_uv[i * 3 + 2] = f4(s0.x, s0.y, s0.z, 0.0f);
+            put_mat((int)i, p.mat);
+        }
+    });
+    if (bad_plane >= 0) return c->fail(RT_ERR_ARG, "plane %d: vertex range out of bounds", bad_plane.load());
     // cubes: rotation sines/cosines from the host libm, exactly the values cube.cpp:301-313 and :328-346 compute per ray
     c->h_file_cubes.assign((size_t)nc * 6, f4(0, 0, 0, 0));
-    for (int i = 0; i < nc; ++i) {
-        const rt_cube& q = sc->cubes[i];
-        float ix = -q.rotation[0], iy = -q.rotation[1], iz = -q.rotation[2];
-        float4* w = &c->h_file_cubes[(size_t)i * 6];
-        w[0] = f4(q.start[0], q.start[1], q.start[2], q.scale);
-        w[1] = f4(q.end[0], q.end[1], q.end[2], 1.0f / q.scale);
-        w[2] = f4(std::cos(q.rotation[0]), std::sin(q.rotation[0]), std::cos(q.rotation[1]), std::sin(q.rotation[1]));
-        w[3] = f4(std::cos(q.rotation[2]), std::sin(q.rotation[2]), as_f(np + i), 0.0f);
-        w[4] = f4(std::cos(iz), std::sin(iz), std::cos(iy), std::sin(iy));
-        w[5] = f4(std::cos(ix), std::sin(ix), 0.0f, 0.0f);
-        if (put_mat(np + i, q.mat) != RT_OK) return c->fail(RT_ERR_ARG, "cube %d: texture id out of range", i);
-    }
+    rt_parallel_for((size_t)nc, 4096, [&](size_t lo, size_t hi, int) {
+        for (size_t i = lo; i < hi; ++i) {
+            const rt_cube& q = sc->cubes[i];
+            float ix = -q.rotation[0], iy = -q.rotation[1], iz = -q.rotation[2];
+            float4* w = &c->h_file_cubes[i * 6];
+            w[0] = f4(q.start[0], q.start[1], q.start[2], q.scale);
+            w[1] = f4(q.end[0], q.end[1], q.end[2], 1.0f / q.scale);
+            w[2] = f4(std::cos(q.rotation[0]), std::sin(q.rotation[0]), std::cos(q.rotation[1]), std::sin(q.rotation[1]));
+            w[3] = f4(std::cos(q.rotation[2]), std::sin(q.rotation[2]), as_f(np + (int)i), 0.0f);
+            w[4] = f4(std::cos(iz), std::sin(iz), std::cos(iy), std::sin(iy));
+            w[5] = f4(std::cos(ix), std::sin(ix), 0.0f, 0.0f);
+            put_mat(np + (int)i, q.mat);
+        }
+    });
     c->h_file_spheres.assign((size_t)ns * 2, f4(0, 0, 0, 0));
-    for (int i = 0; i < ns; ++i) {
-        const rt_sphere& s = sc->spheres[i];
-        c->h_file_spheres[(size_t)i * 2 + 0] = f4(s.start[0], s.start[1], s.start[2], s.radius);
-        c->h_file_spheres[(size_t)i * 2 + 1] = f4(s.end[0], s.end[1], s.end[2], as_f(np + nc + i));
-        if (put_mat(np + nc + i, s.mat) != RT_OK) return c->fail(RT_ERR_ARG, "sphere %d: texture id out of range", i);
-    }
+    rt_parallel_for((size_t)ns, 16384, [&](size_t lo, size_t hi, int) {
+        for (size_t i = lo; i < hi; ++i) {
+            const rt_sphere& s = sc->spheres[i];
+            c->h_file_spheres[i * 2 + 0] = f4(s.start[0], s.start[1], s.start[2], s.radius);
+            c->h_file_spheres[i * 2 + 1] = f4(s.end[0], s.end[1], s.end[2], as_f(np + nc + (int)i));
+            put_mat(np + nc + (int)i, s.mat);
+        }
+    });
+    if (bad_tex >= 0) return c->fail(RT_ERR_ARG, "primitive %d (planes, cubes, spheres in file order): texture id out of range", bad_tex.load());
+    c->any_reflective = any_refl != 0; c->any_transparent = any_transp != 0;
+
     std::vector<float4> lights((size_t)sc->n_lights);
     for (int i = 0; i < sc->n_lights; ++i)
         lights[i] = f4(sc->lights[i].location[0], sc->lights[i].location[1], sc->lights[i].location[2], sc->lights[i].rad_intensity);
@@ -430,56 +452,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
             texels[base + k] = f4(tx.rgb[3 * k] / 255.0f, tx.rgb[3 * k + 1] / 255.0f, tx.rgb[3 * k + 2] / 255.0f, 0.0f);
     }
 
-    // true bounds, the sphere around all of them, and the second-level hierarchy over the whole file-order set
-    c->tb_planes.resize((size_t)np); c->tb_cubes.resize((size_t)nc); c->tb_spheres.resize((size_t)ns);
-    Box3 all; all.clear();
-    for (int i = 0; i < np; ++i) { c->tb_planes[i] = true_box(sc->planes[i], sc->plane_verts); all.add(c->tb_planes[i]); }
-    for (int i = 0; i < nc; ++i) { c->tb_cubes[i] = true_box(sc->cubes[i]); all.add(c->tb_cubes[i]); }
-    for (int i = 0; i < ns; ++i) { c->tb_spheres[i] = true_box(sc->spheres[i]); all.add(c->tb_spheres[i]); }
-    if (ns > 0) {
-        // The sphere test forms |l|^2 - tca^2 in float (sphere.cpp:131-139): a difference of two numbers of the size
-        // of the squared distance to the centre, so far-away spheres are reported hit by rays that pass a little
-        // outside them.  With e = 6e-7 * Dmax^2 bounding that rounding error (Dmax = largest distance between a ray
-        // origin - the camera or a point of the scene - and a centre), a reported hit lies within sqrt(r^2 + e) of
-        // the centre; the boxes that steer the second-level hierarchy are enlarged accordingly.
-        Box3 reach = all; reach.add(sc->camera.location);
-        double diag2 = 0.0;
-        for (int k = 0; k < 3; ++k) { double d = (double)reach.mx[k] - (double)reach.mn[k] + 0.05; diag2 += d * d; }
-        const double e = 6e-7 * diag2;
-        all.clear();
-        for (int i = 0; i < np; ++i) all.add(c->tb_planes[i]);
-        for (int i = 0; i < nc; ++i) all.add(c->tb_cubes[i]);
-        for (int i = 0; i < ns; ++i) {
-            const double r = std::fabs((double)sc->spheres[i].radius);
-            const float extra = (float)(std::sqrt(r * r + e) - r) * 1.01f;
-            Box3& b = c->tb_spheres[i];
-            if (extra < INFINITY) for (int k = 0; k < 3; ++k) { b.mn[k] -= extra; b.mx[k] += extra; }
-            all.add(b);
-        }
-    }
-    float centre[3] = { 0.0f, 0.0f, 0.0f }, radius = 1.0f;
-    if (np + nc + ns > 0) {
-        float half[3];
-        for (int k = 0; k < 3; ++k) { centre[k] = 0.5f * (all.mn[k] + all.mx[k]); half[k] = 0.5f * (all.mx[k] - all.mn[k]); }
-        radius = std::sqrt(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]);
-        if (!(radius < 1e30f)) { radius = 1e30f; for (int k = 0; k < 3; ++k) if (!(std::fabs(centre[k]) < 1e30f)) centre[k] = 0.0f; }
-    }
-    c->h_sub_nodes_file.clear(); c->h_sub_entries_file.clear(); c->file_sub_root = -1;
-    if (np + nc + ns > c->sub_min_group) {
-        if (np >= (1 << 30) || nc >= (1 << 30) || ns >= (1 << 30)) return c->fail(RT_ERR_ARG, "too many primitives of one class");
-        std::vector<SubItem> items; items.reserve((size_t)(np + nc + ns));
-        for (int i = 0; i < np; ++i) items.push_back(make_item(0, i, c->tb_planes[i]));
-        for (int i = 0; i < nc; ++i) items.push_back(make_item(1, i, c->tb_cubes[i]));
-        for (int i = 0; i < ns; ++i) items.push_back(make_item(2, i, c->tb_spheres[i]));
-        SubBuilder sb{ c->h_sub_nodes_file, c->h_sub_entries_file };
-        SubRef root = sb.build(items, 0, items.size(), 0);
-        if (sb.max_depth + 2 > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_STACK - 2);
-        c->file_sub_root = root.ref;
-    }
-
     hipStream_t s = c->stream;
-    RT_HIP(c, c->d_sub_nodes.upload(c->h_sub_nodes_file, s));
-    RT_HIP(c, c->d_sub_entries.upload(c->h_sub_entries_file, s));
     RT_HIP(c, c->d_mats.upload(mats, s));
     RT_HIP(c, c->d_plane_uv.upload(plane_uv, s));
     RT_HIP(c, c->d_verts.upload(c->h_verts_sorted, s));
@@ -496,10 +469,86 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
     d.fileset.planes = c->d_file_planes.p; d.fileset.verts = c->d_verts.p; d.fileset.cubes = c->d_file_cubes.p;
     d.fileset.spheres = c->d_file_spheres.p; d.fileset.n_planes = np; d.fileset.n_cubes = nc; d.fileset.n_spheres = ns;
     d.leafset = d.fileset;
+
+    // True bounds, the sphere around all of them, and the second-level hierarchy over the whole file-order set.
+    // The sphere test forms |l|^2 - tca^2 in float (sphere.cpp:131-139): a difference of two numbers of the size of
+    // the squared distance to the centre, so far-away spheres are reported hit by rays that pass a little outside
+    // them.  With e = 6e-7 * Dmax^2 bounding that rounding error (Dmax = largest distance between a ray origin - the
+    // camera or a point of the scene - and a centre), a reported hit lies within sqrt(r^2 + e) of the centre; the
+    // boxes that steer the second-level hierarchy are enlarged accordingly.
+    auto sphere_allowance = [&](Box3 reach) {
+        reach.add(sc->camera.location);
+        double diag2 = 0.0;
+        for (int k = 0; k < 3; ++k) { double dd = (double)reach.mx[k] - (double)reach.mn[k] + 0.05; diag2 += dd * dd; }
+        return 6e-7 * diag2;
+    };
+    Box3 all; all.clear();
+    c->sphere_e = 0.0; c->file_sub_root = -1; c->n_file_nodes = 0; c->n_file_entries = 0;
+    c->h_sub_nodes_file.clear(); c->h_sub_entries_file.clear();
+    c->tb_planes.clear(); c->tb_cubes.clear(); c->tb_spheres.clear();
+    if (on_device) {
+        float b6[6];
+        RT_HIP(c, rt_build_scene_bounds(s, d.fileset, b6));
+        Box3 raw; for (int k = 0; k < 3; ++k) { raw.mn[k] = b6[k]; raw.mx[k] = b6[3 + k]; }
+        if (ns > 0) c->sphere_e = sphere_allowance(raw);
+        BuildGroup g{}; g.pn = np; g.cn = nc; g.sn = ns; g.n = np + nc + ns; g.depth = rt_build_depth(g.n);
+        if (g.depth + 2 > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_STACK - 2);
+        c->n_file_nodes = (1ll << g.depth) - 1; c->n_file_entries = g.n;
+        RT_HIP(c, c->d_sub_nodes_file.resize((size_t)c->n_file_nodes * 4));
+        RT_HIP(c, c->d_sub_entries_file.resize((size_t)c->n_file_entries));
+        float fin[6];
+        RT_HIP(c, rt_build_hierarchies(s, d.fileset, &g, 1, g.n, c->sphere_e, c->d_sub_nodes_file.p, c->d_sub_entries_file.p, 0, fin));
+        for (int k = 0; k < 3; ++k) { all.mn[k] = fin[k]; all.mx[k] = fin[3 + k]; }
+        c->file_sub_root = 0;
+        // the host copies of the records are only needed by the host build
+        std::vector<float4>().swap(c->h_file_planes); std::vector<float4>().swap(c->h_file_cubes);
+        std::vector<float4>().swap(c->h_file_spheres); std::vector<float4>().swap(c->h_verts_sorted);
+    } else {
+        c->tb_planes.resize((size_t)np); c->tb_cubes.resize((size_t)nc); c->tb_spheres.resize((size_t)ns);
+        for (int i = 0; i < np; ++i) { c->tb_planes[i] = true_box(sc->planes[i], sc->plane_verts); all.add(c->tb_planes[i]); }
+        for (int i = 0; i < nc; ++i) { c->tb_cubes[i] = true_box(sc->cubes[i]); all.add(c->tb_cubes[i]); }
+        for (int i = 0; i < ns; ++i) { c->tb_spheres[i] = true_box(sc->spheres[i]); all.add(c->tb_spheres[i]); }
+        if (ns > 0) {
+            const double e = sphere_allowance(all);
+            c->sphere_e = e;
+            all.clear();
+            for (int i = 0; i < np; ++i) all.add(c->tb_planes[i]);
+            for (int i = 0; i < nc; ++i) all.add(c->tb_cubes[i]);
+            for (int i = 0; i < ns; ++i) {
+                const double r = std::fabs((double)sc->spheres[i].radius);
+                const float extra = (float)(std::sqrt(r * r + e) - r) * 1.01f;
+                Box3& b = c->tb_spheres[i];
+                if (extra < INFINITY) for (int k = 0; k < 3; ++k) { b.mn[k] -= extra; b.mx[k] += extra; }
+                all.add(b);
+            }
+        }
+        if (np + nc + ns > c->sub_min_group) {
+            std::vector<SubItem> items; items.reserve((size_t)(np + nc + ns));
+            for (int i = 0; i < np; ++i) items.push_back(make_item(0, i, c->tb_planes[i]));
+            for (int i = 0; i < nc; ++i) items.push_back(make_item(1, i, c->tb_cubes[i]));
+            for (int i = 0; i < ns; ++i) items.push_back(make_item(2, i, c->tb_spheres[i]));
+            SubBuilder sb{ c->h_sub_nodes_file, c->h_sub_entries_file };
+            SubRef root = sb.build(items, 0, items.size(), 0);
+            if (sb.max_depth + 2 > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_STACK - 2);
+            c->file_sub_root = root.ref;
+        }
+        c->n_file_nodes = (long long)(c->h_sub_nodes_file.size() / 4); c->n_file_entries = (long long)c->h_sub_entries_file.size();
+        RT_HIP(c, c->d_sub_nodes_file.upload(c->h_sub_nodes_file, s));
+        RT_HIP(c, c->d_sub_entries_file.upload(c->h_sub_entries_file, s));
+        RT_HIP(c, hipStreamSynchronize(s));
+    }
+    float centre[3] = { 0.0f, 0.0f, 0.0f }, radius = 1.0f;
+    if (np + nc + ns > 0) {
+        float half[3];
+        for (int k = 0; k < 3; ++k) { centre[k] = 0.5f * (all.mn[k] + all.mx[k]); half[k] = 0.5f * (all.mx[k] - all.mn[k]); }
+        radius = std::sqrt(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]);
+        if (!(radius < 1e30f)) { radius = 1e30f; for (int k = 0; k < 3; ++k) if (!(std::fabs(centre[k]) < 1e30f)) centre[k] = 0.0f; }
+    }
+
     d.mats = c->d_mats.p; d.plane_uv = c->d_plane_uv.p; d.tex_desc = c->d_tex_desc.p; d.texels = c->d_texels.p;
     d.lights = c->d_lights.p; d.n_lights = sc->n_lights;
-    d.sub_nodes = c->h_sub_nodes_file.empty() ? nullptr : c->d_sub_nodes.p;
-    d.sub_entries = c->d_sub_entries.p; d.file_sub_root = c->file_sub_root;
+    d.sub_nodes = c->n_file_nodes ? c->d_sub_nodes_file.p : nullptr;
+    d.sub_entries = c->d_sub_entries_file.p; d.file_sub_root = c->file_sub_root;
     for (int k = 0; k < 3; ++k) d.center[k] = centre[k];
     d.radius = radius;
     c->have_scene = true;
@@ -516,10 +565,13 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->have_bvh = false;
     c->drop_graphs();
-    c->scene.n_nodes = 0; c->scene.n_leaves = 0;
+    DevScene& d = c->scene;
+    d.n_nodes = 0; d.n_leaves = 0;
+    d.sub_nodes = c->n_file_nodes ? c->d_sub_nodes_file.p : nullptr; d.sub_entries = c->d_sub_entries_file.p;
     if (!nodes || n_nodes <= 0) return RT_OK;
     if (n_prim_ids < 0 || (n_prim_ids && !prim_ids)) return c->fail(RT_ERR_ARG, "bad prim_ids");
-    const int np = (int)c->planes.size(), nc = (int)c->cubes.size(), ns = (int)c->spheres.size();
+    const int np = c->np, nc = c->nc, ns = c->ns;
+    const bool on_device = c->built_on_device;
 
     // Re-lay the pointer tree out for a stackless walk.  The reference's traversal keeps the hit of the last leaf
     // (in left-to-right depth-first order) that has one, so the device visits right children first and stops at the
@@ -528,12 +580,10 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
     // box, as that child (AABB::fromPoints over the same objects): such chains are folded into one test.
     struct Out { float mn[3], mx[3]; int skip, leaf; };
     std::vector<Out> out; std::vector<int4> leaves;
-    std::vector<float4> lp, lc, ls;
-    std::vector<float4> sub_nodes = c->h_sub_nodes_file;      // the file-order hierarchy keeps its node indices
-    std::vector<int> sub_entries = c->h_sub_entries_file;
-    std::vector<SubItem> items;
+    std::vector<LeafGather> gather;                           // per leaf: where its ids are and where its records go
     std::vector<char> seen((size_t)n_nodes, 0);
     std::string problem;
+    long long lp_n = 0, lc_n = 0, ls_n = 0;
     // iterative pre-order, right child first
     struct Item { int node; int phase; int out_idx; };
     std::vector<Item> st; st.push_back({ 0, 0, -1 });
@@ -558,44 +608,14 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
         Out o{}; std::memcpy(o.mn, n.box_min, 12); std::memcpy(o.mx, n.box_max, 12); o.skip = 0; o.leaf = -1;
         int my = (int)out.size();
         if (n.left < 0 && n.right < 0) {
-            int cnt = n.n_planes + n.n_cubes + n.n_spheres;
+            long long cnt = (long long)n.n_planes + n.n_cubes + n.n_spheres;
             if (n.n_planes < 0 || n.n_cubes < 0 || n.n_spheres < 0 || n.first_prim < 0 || n.first_prim + cnt > n_prim_ids) { problem = "leaf range out of bounds"; break; }
+            if (lp_n + n.n_planes > 0x3fffffffll || lc_n + n.n_cubes > 0x3fffffffll || ls_n + n.n_spheres > 0x3fffffffll) { problem = "too many primitives in leaves"; break; }
             o.leaf = (int)(leaves.size() / 2);
-            leaves.push_back(make_int4((int)(lp.size() / 3), n.n_planes, (int)(lc.size() / 6), n.n_cubes));
-            leaves.push_back(make_int4((int)(ls.size() / 2), n.n_spheres, -1, 0));
-            const size_t leaf_rec = leaves.size() - 1;
-            const int lp0 = (int)(lp.size() / 3), lc0 = (int)(lc.size() / 6), ls0 = (int)(ls.size() / 2);
-            const int32_t* ids = prim_ids + n.first_prim;
-            for (int k = 0; k < n.n_planes; ++k) {
-                int id = ids[k]; if (id < 0 || id >= np) { problem = "plane id out of range"; break; }
-                const rt_plane& p = c->planes[(size_t)id];
-                const float* v0 = &c->plane_verts[(size_t)p.first_vert * 3];
-                // Leaves hold copies made before any ray was traced (bvh.cpp:113, :70): the plane offset comes
-                // from the first vertex in FILE order.
-                lp.push_back(c->h_file_planes[(size_t)id * 3 + 0]);
-                float4 w1 = c->h_file_planes[(size_t)id * 3 + 1];
-                lp.push_back(f4(v0[0], v0[1], v0[2], w1.w));
-                lp.push_back(c->h_file_planes[(size_t)id * 3 + 2]);
-            }
-            for (int k = 0; k < n.n_cubes && problem.empty(); ++k) {
-                int id = ids[n.n_planes + k]; if (id < 0 || id >= nc) { problem = "cube id out of range"; break; }
-                for (int q = 0; q < 6; ++q) lc.push_back(c->h_file_cubes[(size_t)id * 6 + q]);
-            }
-            for (int k = 0; k < n.n_spheres && problem.empty(); ++k) {
-                int id = ids[n.n_planes + n.n_cubes + k]; if (id < 0 || id >= ns) { problem = "sphere id out of range"; break; }
-                for (int q = 0; q < 2; ++q) ls.push_back(c->h_file_spheres[(size_t)id * 2 + q]);
-            }
-            if (!problem.empty()) break;
-            if (cnt > c->sub_min_group) {           // second-level hierarchy over this leaf's primitives (leaf-order indices)
-                items.clear(); items.reserve((size_t)cnt);
-                for (int k = 0; k < n.n_planes; ++k) items.push_back(make_item(0, lp0 + k, c->tb_planes[(size_t)ids[k]]));
-                for (int k = 0; k < n.n_cubes; ++k) items.push_back(make_item(1, lc0 + k, c->tb_cubes[(size_t)ids[n.n_planes + k]]));
-                for (int k = 0; k < n.n_spheres; ++k) items.push_back(make_item(2, ls0 + k, c->tb_spheres[(size_t)ids[n.n_planes + n.n_cubes + k]]));
-                SubBuilder sb{ sub_nodes, sub_entries };
-                SubRef root = sb.build(items, 0, items.size(), 0);
-                if (sb.max_depth + 2 > RT_SUB_STACK) { problem = "second-level hierarchy too deep"; break; }
-                leaves[leaf_rec].z = root.ref;
-            }
+            leaves.push_back(make_int4((int)lp_n, n.n_planes, (int)lc_n, n.n_cubes));
+            leaves.push_back(make_int4((int)ls_n, n.n_spheres, -1, 0));
+            gather.push_back(LeafGather{ n.first_prim, n.n_planes, n.n_cubes, n.n_spheres, (int)lp_n, (int)lc_n, (int)ls_n, 0 });
+            lp_n += n.n_planes; lc_n += n.n_cubes; ls_n += n.n_spheres;
             out.push_back(o);
             out[(size_t)my].skip = my + 1;
         } else {
@@ -609,6 +629,21 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
     if (out.size() > RT_MAX_LDS_NODES || leaves.size() / 2 > RT_MAX_LDS_LEAVES)
         return c->fail(RT_ERR_CAPACITY, "BVH has %zu nodes / %zu leaves after folding; at most %d / %d fit the on-chip copy",
                        out.size(), leaves.size() / 2, RT_MAX_LDS_NODES, RT_MAX_LDS_LEAVES);
+    // every id a leaf names must exist: the copy kernels index the file-order arrays with them
+    {
+        std::atomic<int> bad{ -1 };
+        rt_parallel_for(gather.size(), 1, [&](size_t lo, size_t hi, int) {
+            for (size_t g = lo; g < hi; ++g) {
+                const LeafGather& L = gather[g];
+                const int32_t* ids = prim_ids + L.first_id;
+                for (int k = 0; k < L.n_planes; ++k) if (ids[k] < 0 || ids[k] >= np) bad = 0;
+                for (int k = 0; k < L.n_cubes; ++k) if (ids[L.n_planes + k] < 0 || ids[L.n_planes + k] >= nc) bad = 1;
+                for (int k = 0; k < L.n_spheres; ++k) if (ids[L.n_planes + L.n_cubes + k] < 0 || ids[L.n_planes + L.n_cubes + k] >= ns) bad = 2;
+            }
+        });
+        static const char* const kind[3] = { "plane", "cube", "sphere" };
+        if (bad >= 0) return c->fail(RT_ERR_ARG, "rt_upload_bvh: %s id out of range", kind[bad.load()]);
+    }
 
     std::vector<float4> dn(out.size() * 2);
     for (size_t i = 0; i < out.size(); ++i) {
@@ -616,21 +651,83 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
         dn[2 * i + 1] = f4(out[i].mx[0], out[i].mx[1], out[i].mx[2], as_f(out[i].leaf));
     }
     hipStream_t s = c->stream;
+    DevPrimSet leafset = d.fileset;
+    leafset.n_planes = (int)lp_n; leafset.n_cubes = (int)lc_n; leafset.n_spheres = (int)ls_n;
+    long long total_nodes = c->n_file_nodes, total_entries = c->n_file_entries;
+    if (on_device) {
+        // leaf-order copies of the records, then one build over all leaves that are large enough
+        RT_HIP(c, c->d_prim_ids.resize((size_t)n_prim_ids));
+        if (n_prim_ids) RT_HIP(c, hipMemcpyAsync(c->d_prim_ids.p, prim_ids, sizeof(int32_t) * (size_t)n_prim_ids, hipMemcpyHostToDevice, s));
+        RT_HIP(c, c->d_leaf_planes.resize((size_t)lp_n * 3)); RT_HIP(c, c->d_leaf_cubes.resize((size_t)lc_n * 6));
+        RT_HIP(c, c->d_leaf_spheres.resize((size_t)ls_n * 2));
+        RT_HIP(c, rt_build_gather_leaves(s, d.fileset, c->d_prim_ids.p, gather.data(), (int)gather.size(),
+                                         c->d_leaf_planes.p, c->d_leaf_cubes.p, c->d_leaf_spheres.p));
+        leafset.planes = c->d_leaf_planes.p; leafset.cubes = c->d_leaf_cubes.p; leafset.spheres = c->d_leaf_spheres.p;
+        std::vector<BuildGroup> groups; long long n_items = 0;
+        for (size_t g = 0; g < gather.size(); ++g) {
+            const LeafGather& L = gather[g];
+            const long long cnt = (long long)L.n_planes + L.n_cubes + L.n_spheres;
+            if (cnt <= c->sub_min_group) continue;
+            BuildGroup b{}; b.p0 = L.lp0; b.pn = L.n_planes; b.c0 = L.lc0; b.cn = L.n_cubes; b.s0 = L.ls0; b.sn = L.n_spheres;
+            b.n = (int)cnt; b.depth = rt_build_depth(cnt); b.item_base = (int)n_items; b.node_base = (int)total_nodes;
+            if (b.depth + 2 > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_STACK - 2);
+            leaves[2 * g + 1].z = b.node_base;
+            n_items += cnt; total_nodes += (1ll << b.depth) - 1;
+            groups.push_back(b);
+        }
+        total_entries += n_items;
+        if (total_nodes > 0x7fffffffll / 4 || total_entries > 0x7fffffffll) return c->fail(RT_ERR_CAPACITY, "second-level hierarchies too large");
+        RT_HIP(c, c->d_sub_nodes.resize((size_t)total_nodes * 4)); RT_HIP(c, c->d_sub_entries.resize((size_t)total_entries));
+        if (c->n_file_nodes) RT_HIP(c, hipMemcpyAsync(c->d_sub_nodes.p, c->d_sub_nodes_file.p, sizeof(float4) * 4 * (size_t)c->n_file_nodes, hipMemcpyDeviceToDevice, s));
+        if (c->n_file_entries) RT_HIP(c, hipMemcpyAsync(c->d_sub_entries.p, c->d_sub_entries_file.p, sizeof(int) * (size_t)c->n_file_entries, hipMemcpyDeviceToDevice, s));
+        RT_HIP(c, rt_build_hierarchies(s, leafset, groups.data(), (int)groups.size(), n_items, c->sphere_e,
+                                       c->d_sub_nodes.p, c->d_sub_entries.p, c->n_file_entries, nullptr));
+    } else {
+        std::vector<float4> lp, lc, ls;
+        std::vector<float4> sub_nodes = c->h_sub_nodes_file;      // the file-order hierarchy keeps its node indices
+        std::vector<int> sub_entries = c->h_sub_entries_file;
+        std::vector<SubItem> items;
+        lp.reserve((size_t)lp_n * 3); lc.reserve((size_t)lc_n * 6); ls.reserve((size_t)ls_n * 2);
+        for (size_t g = 0; g < gather.size(); ++g) {
+            const LeafGather& L = gather[g];
+            const int32_t* ids = prim_ids + L.first_id;
+            for (int k = 0; k < L.n_planes; ++k) {
+                const int id = ids[k];
+                const float4 w1 = c->h_file_planes[(size_t)id * 3 + 1], w2 = c->h_file_planes[(size_t)id * 3 + 2];
+                lp.push_back(c->h_file_planes[(size_t)id * 3 + 0]);
+                lp.push_back(f4(w2.y, w2.z, w2.w, w1.w));        // offset vertex = first vertex in file order
+                lp.push_back(f4(w2.x, 0.0f, 0.0f, 0.0f));
+            }
+            for (int k = 0; k < L.n_cubes; ++k) for (int q = 0; q < 6; ++q) lc.push_back(c->h_file_cubes[(size_t)ids[L.n_planes + k] * 6 + q]);
+            for (int k = 0; k < L.n_spheres; ++k) for (int q = 0; q < 2; ++q) ls.push_back(c->h_file_spheres[(size_t)ids[L.n_planes + L.n_cubes + k] * 2 + q]);
+            const int cnt = L.n_planes + L.n_cubes + L.n_spheres;
+            if (cnt > c->sub_min_group) {           // second-level hierarchy over this leaf's primitives (leaf-order indices)
+                items.clear(); items.reserve((size_t)cnt);
+                for (int k = 0; k < L.n_planes; ++k) items.push_back(make_item(0, L.lp0 + k, c->tb_planes[(size_t)ids[k]]));
+                for (int k = 0; k < L.n_cubes; ++k) items.push_back(make_item(1, L.lc0 + k, c->tb_cubes[(size_t)ids[L.n_planes + k]]));
+                for (int k = 0; k < L.n_spheres; ++k) items.push_back(make_item(2, L.ls0 + k, c->tb_spheres[(size_t)ids[L.n_planes + L.n_cubes + k]]));
+                SubBuilder sb{ sub_nodes, sub_entries };
+                SubRef root = sb.build(items, 0, items.size(), 0);
+                if (sb.max_depth + 2 > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_STACK - 2);
+                leaves[2 * g + 1].z = root.ref;
+            }
+        }
+        total_nodes = (long long)(sub_nodes.size() / 4); total_entries = (long long)sub_entries.size();
+        RT_HIP(c, c->d_leaf_planes.upload(lp, s));
+        RT_HIP(c, c->d_leaf_cubes.upload(lc, s));
+        RT_HIP(c, c->d_leaf_spheres.upload(ls, s));
+        RT_HIP(c, c->d_sub_nodes.upload(sub_nodes, s));
+        RT_HIP(c, c->d_sub_entries.upload(sub_entries, s));
+        RT_HIP(c, hipStreamSynchronize(s));
+        leafset.planes = c->d_leaf_planes.p; leafset.cubes = c->d_leaf_cubes.p; leafset.spheres = c->d_leaf_spheres.p;
+    }
     RT_HIP(c, c->d_nodes.upload(dn, s));
     RT_HIP(c, c->d_leaves.upload(leaves, s));
-    RT_HIP(c, c->d_leaf_planes.upload(lp, s));
-    RT_HIP(c, c->d_leaf_cubes.upload(lc, s));
-    RT_HIP(c, c->d_leaf_spheres.upload(ls, s));
-    RT_HIP(c, c->d_sub_nodes.upload(sub_nodes, s));
-    RT_HIP(c, c->d_sub_entries.upload(sub_entries, s));
     RT_HIP(c, hipStreamSynchronize(s));
-    DevScene& d = c->scene;
-    d.sub_nodes = sub_nodes.empty() ? nullptr : c->d_sub_nodes.p; d.sub_entries = c->d_sub_entries.p;
+    d.sub_nodes = total_nodes ? c->d_sub_nodes.p : nullptr; d.sub_entries = c->d_sub_entries.p;
     d.nodes = c->d_nodes.p; d.n_nodes = (int)out.size();
     d.leaves = c->d_leaves.p; d.n_leaves = (int)(leaves.size() / 2);
-    d.leafset.planes = c->d_leaf_planes.p; d.leafset.verts = c->d_verts.p; d.leafset.cubes = c->d_leaf_cubes.p;
-    d.leafset.spheres = c->d_leaf_spheres.p;
-    d.leafset.n_planes = (int)(lp.size() / 3); d.leafset.n_cubes = (int)(lc.size() / 6); d.leafset.n_spheres = (int)(ls.size() / 2);
+    d.leafset = leafset;
     c->have_bvh = true;
     return RT_OK;
 }
@@ -703,7 +800,6 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     if (D > RT_MAX_LEVELS - 4) return c->fail(RT_ERR_ARG, "reflect depth above %d", RT_MAX_LEVELS - 4);
     const int S = AA * DOF * MB;
     const int L = c->n_lights;
-    const int n_prims = (int)(c->planes.size() + c->cubes.size() + c->spheres.size());
 
     DevFrame f; std::memset(&f, 0, sizeof f);
     rt_camera_basis cb = rt_make_camera_basis(c->camera);
@@ -716,7 +812,6 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     f.textures = cfg->textures != 0; f.use_bvh = cfg->bvh != 0; f.motion_blur = cfg->motion_blur != 0; f.max_depth = D;
     // the retry is exact and, through the file-order set's hierarchy, cheap at any scene size: on unless opted out
     int fb = cfg->fallback; if (fb == 0) fb = 1;
-    (void)n_prims;
     f.fallback_full = (fb == 1);
     f.light_radius = cfg->light_radius; f.seed = cfg->seed;
     f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y; f.n_local_tiles = (int)c->local_tiles.size(); f.local_tiles = c->d_local_tiles.p;

@@ -195,6 +195,25 @@ def test_second_level_hierarchy_changes_no_pixel(n, res, flags):
     assert np.array_equal(imgs[0], imgs[1])
 
 
+@pytest.mark.parametrize("n,flags", [(30000, []), (30000, ["-u"]), (20000, ["-m", "-mbs", "1", "-rd", "2", "-grs", "1"]), (300, ["-rd", "2", "-grs", "1"]), (9, [])])
+def test_device_built_hierarchies_equal_host_built(n, flags):
+    """The hierarchies and leaf-order records made on the GPU (Morton sort, perfect trees) and the ones made on the host
+    (median splits) steer the same search: identical frames, identical ray counts."""
+    table = sg.random_prims(n, 7, transparent_frac=0.1)
+    cfg, _ = api.parse_args(flags)
+    got = []
+    for device_build in (1, 0):
+        ls = api.ArrayScene(table, (640, 360))
+        r = api.Renderer(0)
+        r.set_option("device_build", device_build)
+        r.upload(ls, with_bvh=bool(cfg.bvh))
+        img, st = r.render(cfg)
+        got.append((img, (st.shadow_rays, st.reflection_rays, st.refraction_rays)))
+        r.close(); ls.close()
+    assert got[0][0].max() > 0
+    assert np.array_equal(got[0][0], got[1][0]) and got[0][1] == got[1][1]
+
+
 def test_large_scene_windows_match_oracle():
     """50 000 primitives at 1920x1080: the whole frame is out of the oracle's reach, pixel windows are not."""
     n, res = 50000, (1920, 1080)
