@@ -4,6 +4,7 @@
 // the implementation does not: one pass over the scene text with string_views, shape boxes computed once,
 // and an index-partitioning BVH build instead of copying shape vectors per level.
 #include "rt_host.h"
+#include "rt_parallel.h"
 
 #include <algorithm>
 #include <cctype>
@@ -328,10 +329,14 @@ Box sphere_box(const rt_sphere& s) {                       // sphere.cpp:177-188
 
 Box cube_box(const rt_cube& c) {                           // cube.cpp:354-386
     Box b; box_empty(b);
+    // cube.cpp:297-318 evaluates these six float sines/cosines once per corner; they do not depend on the corner
+    const float cx = std::cos(c.rotation[0]), sx = std::sin(c.rotation[0]), cy = std::cos(c.rotation[1]), sy = std::sin(c.rotation[1]);
+    const float cz = std::cos(c.rotation[2]), sz = std::sin(c.rotation[2]);
     const float sg[2] = { -1.0f, 1.0f };
     for (float x : sg) for (float y : sg) for (float z : sg) {
-        float r[3] = { x, y, z };
-        rotate_xyz(r, c.rotation);
+        float y1 = y * cx - z * sx, z1 = y * sx + z * cx;
+        float x2 = x * cy + z1 * sy, z2 = -x * sy + z1 * cy;
+        float r[3] = { x2 * cz - y1 * sz, x2 * sz + y1 * cz, z2 };
         float p[3] = { r[0] * c.scale + c.start[0], r[1] * c.scale + c.start[1], r[2] * c.scale + c.start[2] };
         // The end-position corner is the rotated UNIT corner plus end_location: the reference stores the scaled
         // value into the wrong variable (cube.cpp:378), and ray/box agreement depends on reproducing that.
@@ -396,6 +401,117 @@ struct Builder {
         if (!lp.empty() || !lc.empty() || !ls.empty()) { int c = build(lp, lc, ls, depth_left - 1); nodes[me].left = c; }
         if (!rp.empty() || !rc.empty() || !rs.empty()) { int c = build(rp, rc, rs, depth_left - 1); nodes[me].right = c; }
         return me;
+    }
+};
+
+// The same tree, built level by level over all primitives at once (for scenes of 10^5..10^7 primitives): a primitive
+// carries the path of its node (one bit per level, 1 = right), every level bounds its nodes (per-worker tables merged
+// in primitive order, so the strict compares of aabb.cpp:71-108 see the objects in the reference's order), picks axis
+// and split point per node and extends the paths.  Leaves come out in path order = the recursion's left-to-right
+// order, primitives inside a leaf in file order (a stable partition, like the reference's push_backs).
+struct LevelBuilder {
+    const std::vector<Box>& pbox; const std::vector<Box>& cbox; const std::vector<Box>& sbox;
+    std::vector<rt_bvh_node> nodes;
+    std::vector<int32_t> prim_ids;
+
+    void run(int depth) {
+        const std::vector<Box>* cls[3] = { &pbox, &cbox, &sbox };
+        const size_t n[3] = { pbox.size(), cbox.size(), sbox.size() };
+        const int workers = rt_worker_count();
+        std::vector<uint16_t> path[3];
+        for (int k = 0; k < 3; ++k) path[k].assign(n[k], 0);
+        std::vector<std::vector<Box>> level_box((size_t)depth + 1);       // [level][path]
+        std::vector<std::vector<uint32_t>> level_cnt((size_t)depth + 1);
+        std::vector<Box> tb; std::vector<uint32_t> tc;
+        for (int level = 0; level <= depth; ++level) {
+            const size_t width = (size_t)1 << level;
+            std::vector<Box>& nb = level_box[(size_t)level]; nb.resize(width);
+            std::vector<uint32_t>& cnt = level_cnt[(size_t)level]; cnt.assign(width, 0);
+            for (Box& b : nb) box_empty(b);
+            for (int k = 0; k < 3; ++k) {
+                tb.resize(width * (size_t)workers); tc.assign(width * (size_t)workers, 0);
+                for (Box& b : tb) box_empty(b);
+                const std::vector<Box>& bx = *cls[k]; const std::vector<uint16_t>& pa = path[k];
+                rt_parallel_for(n[k], 8192, [&](size_t lo, size_t hi, int w) {
+                    Box* my = &tb[(size_t)w * width]; uint32_t* mc = &tc[(size_t)w * width];
+                    for (size_t i = lo; i < hi; ++i) { box_add(my[pa[i]], bx[i]); ++mc[pa[i]]; }
+                });
+                for (int w = 0; w < workers; ++w)
+                    for (size_t q = 0; q < width; ++q)
+                        if (tc[(size_t)w * width + q]) { box_add(nb[q], tb[(size_t)w * width + q]); cnt[q] += tc[(size_t)w * width + q]; }
+            }
+            if (level == depth) break;
+            std::vector<int> axis(width, 0); std::vector<float> split(width, 0.0f);
+            for (size_t q = 0; q < width; ++q) {
+                const Box& box = nb[q];
+                int a = 0;                                      // bvh.cpp:123-129
+                if (box.mx[1] - box.mn[1] > box.mx[0] - box.mn[0]) a = 1;
+                if (box.mx[2] - box.mn[2] > box.mx[0] - box.mn[0] && box.mx[2] - box.mn[2] > box.mx[1] - box.mn[1]) a = 2;
+                axis[q] = a; split[q] = (box.mn[a] + box.mx[a]) / 2.0f;   // bvh.cpp:139
+            }
+            for (int k = 0; k < 3; ++k) {
+                const std::vector<Box>& bx = *cls[k]; std::vector<uint16_t>& pa = path[k];
+                rt_parallel_for(n[k], 8192, [&](size_t lo, size_t hi, int) {
+                    for (size_t i = lo; i < hi; ++i) {
+                        const int a = axis[pa[i]];
+                        const bool left = (bx[i].mn[a] + bx[i].mx[a]) / 2.0f < split[pa[i]];
+                        pa[i] = (uint16_t)(pa[i] * 2 + (left ? 0 : 1));
+                    }
+                });
+            }
+        }
+        // leaves: stable counting sort of every class by path
+        const size_t leaves = (size_t)1 << depth;
+        const std::vector<uint32_t>& leaf_cnt = level_cnt[(size_t)depth];
+        std::vector<size_t> first(leaves + 1, 0);
+        for (size_t q = 0; q < leaves; ++q) first[q + 1] = first[q] + leaf_cnt[q];
+        prim_ids.assign(first[leaves], 0);
+        std::vector<uint32_t> class_cnt[3];
+        std::vector<size_t> cursor(leaves);
+        for (size_t q = 0; q < leaves; ++q) cursor[q] = first[q];
+        for (int k = 0; k < 3; ++k) {
+            // per-worker counts -> per-worker start offsets inside every leaf
+            const std::vector<uint16_t>& pa = path[k];
+            std::vector<size_t> off(leaves * (size_t)workers, 0);
+            const size_t chunk_workers = (size_t)workers;
+            rt_parallel_for(n[k], 8192, [&](size_t lo, size_t hi, int w) {
+                size_t* my = &off[(size_t)w * leaves];
+                for (size_t i = lo; i < hi; ++i) ++my[pa[i]];
+            });
+            class_cnt[k].assign(leaves, 0);
+            for (size_t q = 0; q < leaves; ++q) {
+                size_t at = cursor[q];
+                for (size_t w = 0; w < chunk_workers; ++w) { size_t c = off[w * leaves + q]; off[w * leaves + q] = at; at += c; }
+                class_cnt[k][q] = (uint32_t)(at - cursor[q]);
+                cursor[q] = at;
+            }
+            rt_parallel_for(n[k], 8192, [&](size_t lo, size_t hi, int w) {
+                size_t* my = &off[(size_t)w * leaves];
+                for (size_t i = lo; i < hi; ++i) prim_ids[my[pa[i]]++] = (int32_t)i;
+            });
+        }
+        // nodes in the recursion's order (node, left subtree, right subtree); a child exists when it owns a primitive
+        struct Todo { int level; size_t q; int parent; bool right; };
+        std::vector<Todo> st; st.push_back({ 0, 0, -1, false });
+        while (!st.empty()) {
+            Todo t = st.back(); st.pop_back();
+            const int me = (int)nodes.size();
+            rt_bvh_node nd{};
+            const Box& box = level_box[(size_t)t.level][t.q];
+            for (int i = 0; i < 3; ++i) { nd.box_min[i] = box.mn[i]; nd.box_max[i] = box.mx[i]; }
+            nd.left = nd.right = -1;
+            if (t.level == depth) {
+                nd.first_prim = (int32_t)first[t.q];
+                nd.n_planes = (int32_t)class_cnt[0][t.q]; nd.n_cubes = (int32_t)class_cnt[1][t.q]; nd.n_spheres = (int32_t)class_cnt[2][t.q];
+            }
+            nodes.push_back(nd);
+            if (t.parent >= 0) { if (t.right) nodes[(size_t)t.parent].right = me; else nodes[(size_t)t.parent].left = me; }
+            if (t.level < depth) {
+                const std::vector<uint32_t>& cc = level_cnt[(size_t)t.level + 1];
+                if (cc[2 * t.q + 1]) st.push_back({ t.level + 1, 2 * t.q + 1, me, true });    // popped after the left subtree
+                if (cc[2 * t.q]) st.push_back({ t.level + 1, 2 * t.q, me, false });
+            }
+        }
     }
 };
 
@@ -481,15 +597,24 @@ int rt_host_build_bvh(const rt_scene* sc, int32_t max_depth, rt_host_bvh* out) {
     if (!sc || !out || max_depth < 0 || max_depth > 30) return RT_ERR_ARG;
     try {
         std::vector<Box> pbox((size_t)sc->n_planes), cbox((size_t)sc->n_cubes), sbox((size_t)sc->n_spheres);
-        for (int i = 0; i < sc->n_planes; ++i) pbox[i] = plane_box(sc->planes[i], sc->plane_verts);
-        for (int i = 0; i < sc->n_cubes; ++i) cbox[i] = cube_box(sc->cubes[i]);
-        for (int i = 0; i < sc->n_spheres; ++i) sbox[i] = sphere_box(sc->spheres[i]);
-        Builder b{ pbox, cbox, sbox, {}, {} };
-        std::vector<int32_t> pl((size_t)sc->n_planes), cu((size_t)sc->n_cubes), sp((size_t)sc->n_spheres);
-        for (int i = 0; i < sc->n_planes; ++i) pl[i] = i;
-        for (int i = 0; i < sc->n_cubes; ++i) cu[i] = i;
-        for (int i = 0; i < sc->n_spheres; ++i) sp[i] = i;
-        b.build(pl, cu, sp, max_depth);
+        rt_parallel_for(pbox.size(), 8192, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; ++i) pbox[i] = plane_box(sc->planes[i], sc->plane_verts); });
+        rt_parallel_for(cbox.size(), 2048, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; ++i) cbox[i] = cube_box(sc->cubes[i]); });
+        rt_parallel_for(sbox.size(), 8192, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; ++i) sbox[i] = sphere_box(sc->spheres[i]); });
+        struct Result { std::vector<rt_bvh_node> nodes; std::vector<int32_t> prim_ids; } b;
+        const size_t total = pbox.size() + cbox.size() + sbox.size();
+        if (total >= 65536 && max_depth >= 1 && max_depth <= 12 && rt_worker_count() > 1) {
+            LevelBuilder lb{ pbox, cbox, sbox, {}, {} };
+            lb.run(max_depth);
+            b.nodes.swap(lb.nodes); b.prim_ids.swap(lb.prim_ids);
+        } else {
+            Builder rb{ pbox, cbox, sbox, {}, {} };
+            std::vector<int32_t> pl((size_t)sc->n_planes), cu((size_t)sc->n_cubes), sp((size_t)sc->n_spheres);
+            for (int i = 0; i < sc->n_planes; ++i) pl[i] = i;
+            for (int i = 0; i < sc->n_cubes; ++i) cu[i] = i;
+            for (int i = 0; i < sc->n_spheres; ++i) sp[i] = i;
+            rb.build(pl, cu, sp, max_depth);
+            b.nodes.swap(rb.nodes); b.prim_ids.swap(rb.prim_ids);
+        }
         out->n_nodes = (int)b.nodes.size();
         out->nodes = (rt_bvh_node*)std::malloc(sizeof(rt_bvh_node) * std::max<size_t>(1, b.nodes.size()));
         std::memcpy(out->nodes, b.nodes.data(), sizeof(rt_bvh_node) * b.nodes.size());

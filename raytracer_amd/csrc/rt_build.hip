@@ -134,15 +134,53 @@ __global__ __launch_bounds__(256) void k_fill_bounds(unsigned* __restrict__ segb
 }
 
 // Bounds of the item centres of every node of `level` (groups that are still being split).
+// Small nodes (at most 32 items on average): one lane per node loops over the node's items and stores the result.
+// Large nodes: a wavefront walks a contiguous stretch of positions and keeps per-lane bounds for as long as it stays
+// inside one node, so a node costs six atomics per wavefront that touches it; a step that straddles nodes (at most
+// three of them) is reduced node by node.
 __global__ __launch_bounds__(256) void k_node_bounds(const BuildGroup* __restrict__ groups, const unsigned* __restrict__ node_base, int level,
                                                      const float4* __restrict__ boxes, const unsigned* __restrict__ order, unsigned* __restrict__ segb) {
     const BuildGroup g = groups[blockIdx.y];
     if (g.depth <= level) return;
     const unsigned base = node_base[blockIdx.y];
-    for (long long p0 = (long long)blockIdx.x * blockDim.x; p0 < g.n; p0 += (long long)gridDim.x * blockDim.x) {
-        const long long p = p0 + threadIdx.x;
-        const bool active = p < g.n;
-        unsigned node = 0xffffffffu;
+    if ((g.n >> level) <= 32) {
+        const long long width = 1ll << level;
+        for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < width; j += (long long)gridDim.x * blockDim.x) {
+            const long long a = (j * (long long)g.n) >> level, b = ((j + 1) * (long long)g.n) >> level;
+            float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+            for (long long p = a; p < b; ++p) {
+                const size_t item = order[(size_t)g.item_base + (size_t)p];
+                const float4 mn = boxes[2 * item], mx = boxes[2 * item + 1];
+                const float c[3] = { 0.5f * (mn.x + mx.x), 0.5f * (mn.y + mx.y), 0.5f * (mn.z + mx.z) };
+                for (int i = 0; i < 3; ++i) if (c[i] == c[i]) { lo[i] = (c[i] < lo[i]) ? c[i] : lo[i]; hi[i] = (hi[i] < c[i]) ? c[i] : hi[i]; }
+            }
+            unsigned* sb = segb + 6 * ((size_t)base + (size_t)j);
+            for (int i = 0; i < 3; ++i) { sb[i] = enc_ordered(lo[i]); sb[3 + i] = enc_ordered(hi[i]); }
+        }
+        return;
+    }
+    const long long waves = (long long)gridDim.x * (blockDim.x / 64);
+    long long per_wave = (g.n + waves - 1) / waves;
+    per_wave = (per_wave + 63) / 64 * 64;
+    const long long wave = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const long long begin = wave * per_wave, end = (begin + per_wave < g.n) ? begin + per_wave : g.n;
+    const int lane = threadIdx.x & 63;
+    const unsigned NONE = 0xffffffffu;
+    unsigned cur = NONE;
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    auto flush = [&]() {
+        if (cur == NONE) return;
+        for (int i = 0; i < 3; ++i) {
+            float l = wave_min(lo[i]), h = wave_max(hi[i]);
+            if (lane == 0) { atomicMin(&segb[6 * (size_t)cur + i], enc_ordered(l)); atomicMax(&segb[6 * (size_t)cur + 3 + i], enc_ordered(h)); }
+            lo[i] = INFINITY; hi[i] = -INFINITY;
+        }
+        cur = NONE;
+    };
+    for (long long q = begin; q < end; q += 64) {
+        const long long p = q + lane;
+        const bool active = p < end;
+        unsigned node = NONE;
         float c[3] = { 0.0f, 0.0f, 0.0f };
         if (active) {
             const size_t item = order[(size_t)g.item_base + (size_t)p];
@@ -150,22 +188,18 @@ __global__ __launch_bounds__(256) void k_node_bounds(const BuildGroup* __restric
             c[0] = 0.5f * (mn.x + mx.x); c[1] = 0.5f * (mn.y + mx.y); c[2] = 0.5f * (mn.z + mx.z);
             node = base + node_of(p, g.n, level);
         }
-        // a wavefront that lies inside one node (the usual case near the top) reduces first and issues six atomics
-        const unsigned long long act = __ballot(active);
-        if (act == 0ull) continue;
-        const unsigned first = __shfl(node, __ffsll((long long)act) - 1);
-        const bool uniform = __ballot(active && node == first) == act;
-        if (uniform) {
-            for (int i = 0; i < 3; ++i) {
-                const bool ok = active && c[i] == c[i];
-                float lo = wave_min(ok ? c[i] : INFINITY), hi = wave_max(ok ? c[i] : -INFINITY);
-                if ((threadIdx.x & 63) == 0) { atomicMin(&segb[6 * (size_t)first + i], enc_ordered(lo)); atomicMax(&segb[6 * (size_t)first + 3 + i], enc_ordered(hi)); }
-            }
-        } else if (active) {
-            for (int i = 0; i < 3; ++i)
-                if (c[i] == c[i]) { atomicMin(&segb[6 * (size_t)node + i], enc_ordered(c[i])); atomicMax(&segb[6 * (size_t)node + 3 + i], enc_ordered(c[i])); }
+        // the nodes of a step, one after the other (positions are contiguous, so normally there is exactly one)
+        unsigned long long todo = __ballot(active);
+        while (todo) {
+            const unsigned first = __shfl(node, __ffsll((long long)todo) - 1);
+            const bool mine = active && node == first;
+            if (first != cur) { flush(); cur = first; }
+            if (mine)
+                for (int i = 0; i < 3; ++i) if (c[i] == c[i]) { lo[i] = (c[i] < lo[i]) ? c[i] : lo[i]; hi[i] = (hi[i] < c[i]) ? c[i] : hi[i]; }
+            todo &= ~__ballot(mine);
         }
     }
+    flush();
 }
 
 DEVI float dec_ordered_dev(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }

@@ -159,3 +159,20 @@ def test_render_calls_fail_loudly_without_a_gpu_or_scene():
         pytest.skip("GPU present")
     with pytest.raises(api.RtError):
         api.Renderer(0)
+
+
+@pytest.mark.parametrize("n,seed,depth", [(70000, 3, 8), (120000, 5, 11), (66000, 8, 1)])
+def test_threaded_level_build_equals_recursive_build(n, seed, depth, monkeypatch):
+    """Large scenes are built level by level over all primitives with worker threads; nodes (boxes, links, counts,
+    pre-order numbering) and leaf lists must be byte-identical to the recursive build of small scenes."""
+    table = sg.random_prims(n, seed)
+    got = []
+    for threads in ("1", "5"):                      # one worker selects the recursive builder
+        monkeypatch.setenv("RT_AMD_THREADS", threads)
+        ls = api.ArrayScene(table, (64, 36))
+        b = ls.bvh(depth)
+        nodes = np.ctypeslib.as_array(C.cast(b.nodes, C.POINTER(C.c_uint8)), shape=(b.n_nodes * C.sizeof(api.BvhNode),)).copy()
+        ids = np.ctypeslib.as_array(b.prim_ids, shape=(b.n_prim_ids,)).copy()
+        got.append((nodes, ids)); ls.close()
+    assert len(got[0][1]) == n + 1                  # every primitive (and the ground plane) is in exactly one leaf
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
