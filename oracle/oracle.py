@@ -86,6 +86,18 @@ def camera_ray(scene_text: str, x: float, y: float) -> np.ndarray:
     return np.array(list(out), dtype=np.float32)
 
 
+def kat(kind: int, inputs: np.ndarray) -> np.ndarray:
+    """One known-answer record (layout of oracle/ref_kat.cpp) through the restatement."""
+    a = np.ascontiguousarray(inputs, dtype=np.float32)
+    out = np.zeros(19, dtype=np.float32)
+    L = lib()
+    L.orc_kat.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]; L.orc_kat.restype = C.c_int
+    n = L.orc_kat(int(kind), a.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)))
+    if n < 0:
+        raise RuntimeError("orc_kat: unknown kind")
+    return out[:n]
+
+
 def bvh_dump(scene_text: str, flags: list[str] | None = None, cap: int = 4096) -> np.ndarray:
     cfg = parse_args(flags or [])
     out = np.zeros(cap * 12, dtype=np.float32)

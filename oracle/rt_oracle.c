@@ -1196,6 +1196,61 @@ int orc_camera_ray(const char* scene_text, float x, float y, float* out6) {
     return 0;
 }
 
+/* Known-answer replay: one record of oracle/ref_kat.cpp (same input and output layout) through the functions
+ * above.  kind 0 sphere, 1 cube, 2 plane (a fresh object, i.e. what a BVH leaf copy is), 3 box slab test. */
+static void kat_hit(int hit, const Hit* h, int tex, float* out) {
+    out[0] = hit ? 1.0f : 0.0f;
+    for (int i = 1; i < 10; ++i) out[i] = 0.0f;
+    if (!hit) return;
+    out[1] = h->t;
+    for (int i = 0; i < 3; ++i) { out[2 + i] = h->p[i]; out[5 + i] = h->n[i]; }
+    if (tex) { out[8] = h->u; out[9] = h->v; }
+}
+int orc_kat(int kind, const float* in, float* out) {
+    Ray r; memset(&r, 0, sizeof r);
+    for (int i = 0; i < 3; ++i) { r.o[i] = in[i]; r.d[i] = in[3 + i]; }
+    r.time = in[6];
+    const float* a = in + 7;
+    orc_config cfg; orc_default_config(&cfg);
+    Hit h; hit_reset(&h);
+    if (kind == 0) {
+        Sphere s; memset(&s, 0, sizeof s);
+        for (int i = 0; i < 3; ++i) { s.start[i] = a[i]; s.end[i] = a[3 + i]; }
+        s.radius = a[6]; cfg.motionBlur = a[7] != 0.0f; s.m.hasTex = a[8] != 0.0f; cfg.textures = s.m.hasTex;
+        kat_hit(sphere_intersect(&s, &r, &h, &cfg), &h, s.m.hasTex, out);
+        sphere_aabb(&s, out + 10, out + 13);
+        return 16;
+    }
+    if (kind == 1) {
+        Cube c; memset(&c, 0, sizeof c);
+        for (int i = 0; i < 3; ++i) { c.start[i] = a[i]; c.end[i] = a[3 + i]; c.rot[i] = a[6 + i]; }
+        c.scale = a[9]; cfg.motionBlur = a[10] != 0.0f; c.m.hasTex = a[11] != 0.0f; cfg.textures = c.m.hasTex;
+        kat_hit(cube_intersect(&c, &r, &h, &cfg), &h, c.m.hasTex, out);
+        cube_aabb(&c, out + 10, out + 13);
+        return 16;
+    }
+    if (kind == 2) {
+        float vf[4][3], vs[4][3];
+        Plane p; memset(&p, 0, sizeof p);
+        p.n = 4; p.vfile = vf; p.vsorted = vs;
+        for (int k = 0; k < 4; ++k) for (int i = 0; i < 3; ++i) vf[k][i] = a[3 * k + i];
+        p.m.hasTex = a[12] != 0.0f; cfg.textures = p.m.hasTex;
+        plane_calc_normal(&p);
+        plane_sort_winding(&p);
+        kat_hit(plane_intersect_copy(&p, &r, &h), &h, p.m.hasTex, out);
+        for (int i = 0; i < 3; ++i) out[10 + i] = p.normal[i];
+        plane_aabb(&p, out + 13, out + 16);
+        return 19;
+    }
+    if (kind == 3) {
+        float tmin = 0.0f, tmax = 0.0f;
+        int hit = aabb_intersect(a, a + 3, &r, &tmin, &tmax);
+        out[0] = hit ? 1.0f : 0.0f; out[1] = tmin; out[2] = tmax;
+        return 3;
+    }
+    return -1;
+}
+
 static int dump_node(const Node* n, int depth, float* out, int cap, int idx) {
     if (!n) return idx;
     if (idx < cap) {

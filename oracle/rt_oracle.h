@@ -65,6 +65,10 @@ int orc_camera_ray(const char* scene_text, float x, float y, float* out6);
  * Returns the number of nodes (<= cap_nodes) or a negative error. */
 int orc_bvh_dump(const char* scene_text, const orc_config* c, float* out, int cap_nodes);
 
+/* Replays one known-answer record of oracle/ref_kat.cpp (kind, inputs as that file lays them out) through the
+ * restatement's primitive tests and shape boxes; returns the number of floats written to out (<= 19) or -1. */
+int orc_kat(int kind, const float* in, float* out);
+
 const char* orc_last_error(void);
 
 #ifdef __cplusplus

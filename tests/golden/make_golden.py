@@ -4,6 +4,8 @@ Runs only where /root/reference is mounted (`make -C oracle ref` first).  Output
   deterministic.npz : uint8 [H,W,3] image per deterministic case of tests/cases.py
   stochastic.npz    : uint8 [H,W,3] high-sample image per stochastic case
   config1_1080p.npz : the reference's default render of its own scene.json at 1920x1080
+  kat_primitives.npz: known answers of Sphere/Cube/Plane::intersect, their getAABB and AABB::intersect on seeded random
+                      inputs, printed by oracle/_ref/ref_kat (`make -C oracle kat`; `make_golden.py kat` regenerates)
 """
 import sys
 from concurrent.futures import ProcessPoolExecutor
@@ -26,7 +28,18 @@ def run(job):
     return cases.case_id(scene, flags), img.astype(np.uint8), secs
 
 
+def make_kat(n=1500):
+    """Records of oracle/ref_kat.cpp: float32 `kind, n_in, n_out, inputs, outputs`; stored as the raw stream."""
+    import subprocess
+    exe = HERE.parent.parent / "oracle" / "_ref" / "ref_kat"
+    raw = np.frombuffer(subprocess.run([str(exe), str(n)], capture_output=True, check=True).stdout, dtype=np.float32)
+    np.savez_compressed(HERE / "kat_primitives.npz", stream=raw)
+    print(f"kat_primitives: {raw.size} floats")
+
+
 def main():
+    if sys.argv[1:] == ["kat"]:
+        make_kat(); return
     if len(sys.argv) > 1:            # regenerate only the named cases, keep the rest
         for fname, catalogue in (("deterministic.npz", cases.DETERMINISTIC), ("stochastic.npz", cases.STOCHASTIC)):
             have = dict(np.load(HERE / fname))
@@ -46,6 +59,7 @@ def main():
     img, secs, _ = ref_runner.run_ref(cases.reference_scene(1920, 1080), [], TEX)
     np.savez_compressed(HERE / "config1_1080p.npz", image=img.astype(np.uint8), loop_seconds=np.float64(secs))
     print(f"config1 1080p {secs:.2f} s")
+    make_kat()
 
 
 if __name__ == "__main__":
