@@ -183,7 +183,9 @@ int rt_set_stream(rt_ctx* ctx, void* hip_stream);
 /* Implementation options (no counterpart in the reference; none of them changes a rendered value). Set before
  * rt_upload_scene.  "second_level_min_group" = N: groups of more than N primitives (a leaf of the reference's
  * depth-8 tree, or the whole scene for -u) are searched through a second-level hierarchy instead of one by
- * one; default 8, a huge value turns the hierarchy off.  "graphs" = 0/1: whether rt_render_device (without
+ * one; default 8, a huge value turns the hierarchy off.  "device_build" = 0/1: whether those hierarchies and the
+ * leaf-order copies of the primitive records are made by kernels on the device (default 1) or on the host; set
+ * before rt_upload_scene.  "graphs" = 0/1: whether rt_render_device (without
  * statistics) records a frame's launch sequence into a HIP graph on its second call with the same configuration,
  * output pointer and stream, and replays it afterwards; default 1.  "overlap" = 0/1: whether frames rendered
  * without statistics trace the shadow rays of the primary hits on a second, internal stream while the render
