@@ -184,6 +184,8 @@ def main():
             ls = api.ArrayScene(sg.random_prims(wl["n"], 42), (W, H))
     ls = rdist.broadcast_scene(ls, bool(cfg.bvh), 0, on_dev)
     r = api.Renderer(local, workspace_bytes=16 << 30)
+    for kv in filter(None, os.environ.get("RT_BENCH_OPTS", "").split(",")):      # development: name=value library options
+        r.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     r.upload(ls, with_bvh=bool(cfg.bvh))
     r.set_shard(rank, world)
     # Everything of a step runs on one explicit side stream: the render kernels, the RCCL gather (torch orders its

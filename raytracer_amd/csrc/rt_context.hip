@@ -190,6 +190,7 @@ struct rt_ctx {
     std::vector<float4> h_sub_nodes_file; std::vector<int> h_sub_entries_file;
     int file_sub_root = -1;
     int sub_min_group = RT_SUB_MIN_GROUP;    // groups above this size get a second-level hierarchy (rt_set_option)
+    int lds_prims = 1;                       // tiny scenes: primitive records in LDS; 1 = shadow kernel only, 2 = extend too
     int device_build = 1;                    // hierarchies and leaf-order records are made on the GPU (rt_set_option)
     bool built_on_device = false;            // what the current scene's upload used
     long long n_file_nodes = 0, n_file_entries = 0;
@@ -318,6 +319,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
         c->sub_min_group = value > 0x7fffffff ? 0x7fffffff : (int)value;
         return RT_OK;
     }
+    if (std::strcmp(name, "lds_prims") == 0) { c->lds_prims = (int)value; return RT_OK; }
     if (std::strcmp(name, "device_build") == 0) { c->device_build = value != 0; return RT_OK; }
     if (std::strcmp(name, "graphs") == 0) { c->use_graphs = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "overlap") == 0) { c->overlap = value != 0; c->drop_graphs(); return RT_OK; }
@@ -549,6 +551,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
     d.lights = c->d_lights.p; d.n_lights = sc->n_lights;
     d.sub_nodes = c->n_file_nodes ? c->d_sub_nodes_file.p : nullptr;
     d.sub_entries = c->d_sub_entries_file.p; d.file_sub_root = c->file_sub_root;
+    d.n_verts = sc->n_plane_verts;
+    d.lds_prims = (!d.sub_nodes && rt_lds_prim_words(d) <= RT_LDS_PRIM_MAX_WORDS) ? c->lds_prims : 0;
     for (int k = 0; k < 3; ++k) d.center[k] = centre[k];
     d.radius = radius;
     c->have_scene = true;
@@ -728,6 +732,7 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
     d.nodes = c->d_nodes.p; d.n_nodes = (int)out.size();
     d.leaves = c->d_leaves.p; d.n_leaves = (int)(leaves.size() / 2);
     d.leafset = leafset;
+    d.lds_prims = (!d.sub_nodes && rt_lds_prim_words(d) <= RT_LDS_PRIM_MAX_WORDS) ? c->lds_prims : 0;
     c->have_bvh = true;
     return RT_OK;
 }

@@ -14,7 +14,10 @@
 
 // minimum wavefronts per SIMD the register allocator must leave room for (second __launch_bounds__ argument)
 #ifndef RT_EXTEND_WAVES
-#define RT_EXTEND_WAVES 3
+#define RT_EXTEND_WAVES 4           // scenes without second-level hierarchies: a few spills, better co-residency
+#endif
+#ifndef RT_EXTEND_WAVES_SUB
+#define RT_EXTEND_WAVES_SUB 3       // the hierarchy walk needs the registers
 #endif
 #ifndef RT_SHADOW_WAVES
 #define RT_SHADOW_WAVES 4
@@ -509,17 +512,26 @@ DEVI void stage_bvh(const DevScene& sc, float4* s_nodes, int4* s_leaves) {
     __syncthreads();
 }
 
-// Every lane asks for n consecutive slots (n may be 0); one atomic per wavefront.  Must be reached by all 64 lanes.
-DEVI int wave_alloc(int* counter, int n) {
-    const int lane = __lane_id();
-    int incl = n;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
-    int total = __shfl(incl, 63, 64);
-    int base = 0;
-    if (lane == 63 && total > 0) base = atomicAdd(counter, total);
-    base = __shfl(base, 63, 64);
-    return base + incl - n;
+// Tiny scenes (a handful of primitives, no second-level hierarchy): every workgroup also copies the primitive records
+// of both orderings, the polygon vertices and the materials into LDS and redirects the scene's pointers there, so a
+// primitive test costs LDS reads instead of a chain of global-memory round trips.  Words in LDS: rt_lds_prim_words().
+DEVI void stage_prims(DevScene& sc, float4* s_prim) {
+    int o = 0;
+    auto put = [&](const float4* src, int words) -> const float4* {
+        for (int i = threadIdx.x; i < words; i += blockDim.x) s_prim[o + i] = src[i];
+        const float4* p = s_prim + o; o += words; return p;
+    };
+    const int n_mats = 3 * (sc.fileset.n_planes + sc.fileset.n_cubes + sc.fileset.n_spheres);
+    const float4* verts = put(sc.fileset.verts, sc.n_verts);
+    sc.fileset.planes = put(sc.fileset.planes, 3 * sc.fileset.n_planes);
+    sc.fileset.cubes = put(sc.fileset.cubes, 6 * sc.fileset.n_cubes);
+    sc.fileset.spheres = put(sc.fileset.spheres, 2 * sc.fileset.n_spheres);
+    sc.leafset.planes = put(sc.leafset.planes, 3 * sc.leafset.n_planes);
+    sc.leafset.cubes = put(sc.leafset.cubes, 6 * sc.leafset.n_cubes);
+    sc.leafset.spheres = put(sc.leafset.spheres, 2 * sc.leafset.n_spheres);
+    sc.mats = put(sc.mats, n_mats);
+    sc.fileset.verts = verts; sc.leafset.verts = verts;
+    __syncthreads();
 }
 
 // Sum a per-thread count over the workgroup and add it to a 64-bit statistic with one atomic.
@@ -540,7 +552,9 @@ DEVI void block_stat_add(unsigned long long* stat, unsigned long long v, unsigne
 DEVI bool generate_primary(const DevFrame& f, int i, Ray& r, uint32_t& path, int& slot) {
     slot = f.pix_begin + i;
     int tile_local = slot / RT_TILE_PIX, in = slot % RT_TILE_PIX;
-    int gt = f.local_tiles[tile_local];
+    // a wavefront's 64 slots lie in one tile (batches start at multiples of 64): one scalar load, which does not
+    // queue behind the vector stores of the previous round
+    int gt = f.local_tiles[__builtin_amdgcn_readfirstlane(tile_local)];
     int x = (gt % f.tiles_x) * RT_TILE + (in % RT_TILE);
     int y = (gt / f.tiles_x) * RT_TILE + (in / RT_TILE);
     if (x >= f.width || y >= f.height) return false;
@@ -598,16 +612,18 @@ DEVI bool generate_primary(const DevFrame& f, int i, Ray& r, uint32_t& path, int
 // extend: trace one ray per lane to the hit the reference would report, append a hit-tree node, and spawn the
 // reflection / refraction rays of the next level (raytracer.cpp:144-164 for primaries, :373-498 for the spawn).
 // ---------------------------------------------------------------------------------------------------------
-template <bool PRIMARY, bool SUB>
-__global__ __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) void k_extend(DevScene sc, DevFrame f, DevWork w, int level) {
+template <bool PRIMARY, bool SUB, bool LDSP>
+__global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAVES) void k_extend(DevScene sc_arg, DevFrame f, DevWork w, int level) {
     extern __shared__ float4 s_mem[];
+    DevScene sc = sc_arg;
     float4* s_nodes = s_mem;
     int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
     int* s_stack = (int*)(s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves) + threadIdx.x;   // [depth][thread]
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
-    const int count = PRIMARY ? f.pix_count : min(w.ctr[RT_C_LINK_CNT + level], w.link_off[level + 1] - w.link_off[level]);
+    const int count = PRIMARY ? f.pix_count : min(w.ctr[RT_CTR_LINK(level)], w.link_off[level + 1] - w.link_off[level]);
     if ((int)(blockIdx.x * blockDim.x) >= count) return;               // whole workgroup idle
     if (f.use_bvh) stage_bvh(sc, s_nodes, s_leaves);
+    if (LDSP) stage_prims(sc, s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves);
 
     const int link_in = PRIMARY ? 0 : w.link_off[level];
     const int node_base = w.node_off[level], node_cap = w.node_off[level + 1] - w.node_off[level];
@@ -622,6 +638,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) void k_extend(DevScene s
     unsigned long long n_primary = 0, n_refl = 0, n_refr = 0, n_shadow_ref = 0, n_refl_ref = 0, n_refr_ref = 0;
     const unsigned long long shadow_per_hit = (unsigned long long)sc.n_lights * (f.soft_shadows ? f.ss_samples : 1);
 
+    // Order inside a round: loads first (this round's queue entry was fetched during the previous round), then
+    // the trace and all arithmetic, then ONE returning atomic per wavefront that allocates the hit's node and its
+    // children's queue slots together, then every store.  Loads, the atomic's return and stores share one in-order
+    // counter, so anything that waits for a load also waits for all older stores: nothing is loaded after a store
+    // of the same round, and only the atomic stands between the arithmetic and the stores.
+    float4 qa_next = make_float4(0, 0, 0, 0), qb_next = qa_next;
+    if (!PRIMARY) { const int i0 = blockIdx.x * blockDim.x + threadIdx.x; if (i0 < count) { qa_next = qa_in[i0]; qb_next = qb_in[i0]; } }
     for (int it = 0; it < rounds; ++it) {
         const int i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         bool active = i < count;
@@ -630,38 +653,21 @@ __global__ __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) void k_extend(DevScene s
         if (active) {
             if (PRIMARY) active = generate_primary(f, i, r, path, slot);
             else {
-                float4 a = qa_in[i], b = qb_in[i];
+                float4 a = qa_next, b = qb_next;
                 r.o = mk(a.x, a.y, a.z); r.d = mk(a.w, b.x, b.y); r.time = 0.0f;   // secondary rays carry time 0 (ray.h:13)
                 path = (uint32_t)f2i(b.z); mult = (uint32_t)f2i(b.w);
             }
         }
+        if (!PRIMARY) { const int ni = i + stride; if (ni < count) { qa_next = qa_in[ni]; qb_next = qb_in[ni]; } }
         if (PRIMARY && active) ++n_primary;
         Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
         bool hit = active && trace<false, SUB>(sc, f, s_nodes, s_leaves, s_stack, r, !PRIMARY && f.fallback_full, best);
-
-        // one node per hit
-        unsigned long long hm = __ballot(hit);
-        int node = -1;
-        {
-            int total = __popcll(hm);
-            int base = 0;
-            if (__lane_id() == 0 && total) base = atomicAdd(&w.ctr[RT_C_NODE_CNT + level], total);
-            base = __shfl(base, 0, 64);
-            if (hit) node = base + __popcll(hm & ((1ull << __lane_id()) - 1ull));
-        }
-        if (hit && node >= node_cap) { w.stats[RT_S_ERR] = 1; hit = false; }
-        node = hit ? node_base + node : -1;
-        if (!PRIMARY && active) w.link[link_in + i] = node;
 
         int n_children = 0, n_reflect = 0; bool refract = false;
         HitOut h; V3 N = mk(0, 0, 1), rd = mk(0, 0, 1), fd = mk(0, 0, 1); float weight = 0.0f, gloss_angle = 0.0f; bool glossy = false;
         if (hit) {
             n_shadow_ref += shadow_per_hit * mult;
             full_hit(sc, f, r, best, h);
-            w.n_a[node] = make_float4(h.p.x, h.p.y, h.p.z, r.time);
-            w.n_b[node] = make_float4(h.n.x, h.n.y, h.n.z, i2f(h.gid));
-            if (f.textures) w.n_uv[node] = make_float2(h.u, h.v);
-            if (PRIMARY) w.n_pix[node] = slot;
             if (spawn) {
                 float4 m0 = sc.mats[3 * h.gid], m1 = sc.mats[3 * h.gid + 1], m2 = sc.mats[3 * h.gid + 2];
                 float reflectivity = m2.z;                               // raytracer.cpp:374-375, evaluated on the host
@@ -701,8 +707,32 @@ __global__ __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) void k_extend(DevScene s
                 n_children = n_reflect + (refract ? 1 : 0);
             }
         }
-        const int qslot = wave_alloc(&w.ctr[RT_C_LINK_CNT + level + 1], n_children);
+
+        // one node per hit and n_children queue slots, allocated per wavefront with one 64-bit atomic
+        int node = -1, qslot = 0;
+        {
+            const int lane = __lane_id();
+            const unsigned long long hm = __ballot(hit);
+            int incl = n_children;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+            const int total_children = __shfl(incl, 63, 64), total_hits = __popcll(hm);
+            unsigned long long pair = 0;
+            if (lane == 0 && (total_hits | total_children))
+                pair = atomicAdd((unsigned long long*)&w.ctr[RT_CTR_NODE(level)],
+                                 ((unsigned long long)(unsigned)total_children << 32) | (unsigned long long)(unsigned)total_hits);
+            const int base_node = __shfl((int)(unsigned)(pair & 0xffffffffull), 0, 64), base_link = __shfl((int)(unsigned)(pair >> 32), 0, 64);
+            if (hit) node = base_node + __popcll(hm & ((1ull << lane) - 1ull));
+            qslot = base_link + incl - n_children;
+        }
+        if (hit && node >= node_cap) { w.stats[RT_S_ERR] = 1; hit = false; }
+        node = hit ? node_base + node : -1;
+        if (!PRIMARY && active) w.link[link_in + i] = node;
         if (hit) {
+            w.n_a[node] = make_float4(h.p.x, h.p.y, h.p.z, r.time);
+            w.n_b[node] = make_float4(h.n.x, h.n.y, h.n.z, i2f(h.gid));
+            if (f.textures) w.n_uv[node] = make_float2(h.u, h.v);
+            if (PRIMARY) w.n_pix[node] = slot;
             const int first_link = link_out + qslot;
             if (n_children > 0 && qslot + n_children > link_cap) {
                 w.stats[RT_S_ERR] = 1; n_children = 0; n_reflect = 0; refract = false;
@@ -750,9 +780,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) void k_extend(DevScene s
 // blocks.  Soft shadows (raytracer.cpp:534-571): ss_samples rays to points in a ball around the light, blocked
 // when the reported hit is nearer than the sampled point.  Output = number of unblocked samples per (hit, light).
 // ---------------------------------------------------------------------------------------------------------
-template <bool SUB>
-__global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene sc, DevFrame f, DevWork w, int lv_begin, int lv_end) {
+template <bool SUB, bool LDSP>
+__global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene sc_arg, DevFrame f, DevWork w, int lv_begin, int lv_end) {
     extern __shared__ float4 s_mem[];
+    DevScene sc = sc_arg;
     float4* s_nodes = s_mem;
     int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
     int* s_stack = (int*)(s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves) + threadIdx.x;   // [depth][thread]
@@ -763,7 +794,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene s
         for (int lv = 0; lv <= f.max_depth; ++lv) {
             s_first[lv] = acc;
             if (lv < lv_begin || lv > lv_end) continue;                 // this launch covers levels lv_begin..lv_end only
-            acc += min(w.ctr[RT_C_NODE_CNT + lv], w.node_off[lv + 1] - w.node_off[lv]);
+            acc += min(w.ctr[RT_CTR_NODE(lv)], w.node_off[lv + 1] - w.node_off[lv]);
         }
         s_first[f.max_depth + 1] = acc;
     }
@@ -775,6 +806,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene s
     const unsigned count = (unsigned)n_nodes * per;                      // the host keeps hits x lights x samples below 2^31
     if (blockIdx.x * blockDim.x >= count) return;
     if (f.use_bvh) stage_bvh(sc, s_nodes, s_leaves);
+    if (LDSP) stage_prims(sc, s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves);
 
     const unsigned stride = gridDim.x * blockDim.x;
     const unsigned rounds = (count + stride - 1) / stride;
@@ -843,7 +875,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene s
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, DevWork w, int level) {
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
     const int begin = w.node_off[level];
-    const int count = min(w.ctr[RT_C_NODE_CNT + level], w.node_off[level + 1] - w.node_off[level]);
+    const int count = min(w.ctr[RT_CTR_NODE(level)], w.node_off[level + 1] - w.node_off[level]);
     if ((int)(blockIdx.x * blockDim.x) >= count) return;
     const int stride = gridDim.x * blockDim.x;
     const int L = sc.n_lights;
@@ -946,7 +978,9 @@ __global__ void k_finalize(DevFrame f, DevWork w, unsigned char* __restrict__ ou
             out[3 * slot] = (unsigned char)r; out[3 * slot + 1] = (unsigned char)g; out[3 * slot + 2] = (unsigned char)b;
         } else {
             int tile_local = slot / RT_TILE_PIX, in = slot % RT_TILE_PIX;
-            int gt = f.local_tiles[tile_local];
+            // a wavefront's 64 slots lie in one tile (batches start at multiples of 64): one scalar load, which does not
+    // queue behind the vector stores of the previous round
+    int gt = f.local_tiles[__builtin_amdgcn_readfirstlane(tile_local)];
             int x = (gt % f.tiles_x) * RT_TILE + (in % RT_TILE), y = (gt / f.tiles_x) * RT_TILE + (in / RT_TILE);
             if (x < f.width && y < f.height) {
                 size_t o = ((size_t)y * f.width + x) * 3;
@@ -992,24 +1026,29 @@ __global__ void k_assemble(const unsigned char* __restrict__ tiles, int world, i
 static size_t bvh_lds_bytes(const DevScene& sc, const DevFrame& f) {
     size_t b = (size_t)(2 * sc.n_nodes + 2 * sc.n_leaves) * 16;
     if (sc.sub_nodes) b += (size_t)RT_BLOCK * RT_SUB_STACK * sizeof(int);
+    if (sc.lds_prims) b += (size_t)rt_lds_prim_words(sc) * 16;
     return b ? b : 16;
 }
 
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {
     size_t lds = bvh_lds_bytes(sc, f);
     const bool sub = sc.sub_nodes != nullptr;
+    const bool ldsp = !sub && sc.lds_prims > 1;
     if (level == 0) {
-        if (sub) hipLaunchKernelGGL((k_extend<true, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
-        else hipLaunchKernelGGL((k_extend<true, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+        if (sub) hipLaunchKernelGGL((k_extend<true, true, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+        else if (ldsp) hipLaunchKernelGGL((k_extend<true, false, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+        else hipLaunchKernelGGL((k_extend<true, false, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
     } else {
-        if (sub) hipLaunchKernelGGL((k_extend<false, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
-        else hipLaunchKernelGGL((k_extend<false, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+        if (sub) hipLaunchKernelGGL((k_extend<false, true, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+        else if (ldsp) hipLaunchKernelGGL((k_extend<false, false, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+        else hipLaunchKernelGGL((k_extend<false, false, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
     }
 }
 
 void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid) {
-    if (sc.sub_nodes) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w, lv_begin, lv_end);
-    else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w, lv_begin, lv_end);
+    if (sc.sub_nodes) hipLaunchKernelGGL((k_shadow<true, false>), dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w, lv_begin, lv_end);
+    else if (sc.lds_prims) hipLaunchKernelGGL((k_shadow<false, true>), dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w, lv_begin, lv_end);
+    else hipLaunchKernelGGL((k_shadow<false, false>), dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w, lv_begin, lv_end);
 }
 
 void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {

@@ -59,6 +59,8 @@ struct DevScene {
     const float4* sub_nodes;       // second-level hierarchies of all groups (NULL when no group has one)
     const int* sub_entries;
     int file_sub_root;             // second-level root over the whole file-order set, or -1
+    int n_verts;                   // polygon vertices of all planes
+    int lds_prims;                 // tiny scene: kernels keep the primitive records and materials in LDS
     float center[3], radius;       // sphere around the true bounds of everything in the scene
 };
 
@@ -104,17 +106,24 @@ struct DevWork {
 // ctr[] slots: per-level allocation counters, zeroed at the start of every batch.  Each recursion level owns a
 // fixed region of the node and link arenas (offsets in DevWork, sized on the host for the worst-case fan-out), so
 // no kernel ever needs another level's running count and there is no bookkeeping between launches.
-enum {
-    RT_C_NODE_CNT = 0,                         // [level] hits recorded at `level`
-    RT_C_LINK_CNT = RT_MAX_LEVELS,             // [level] secondary rays to trace at `level` (level >= 1)
-    RT_C_TOTAL = 2 * RT_MAX_LEVELS
-};
+// The hits recorded at `level` and the secondary rays they spawn (to be traced at level + 1) sit in the two halves
+// of one aligned 64-bit word, so a wavefront allocates both with a single atomic.
+#define RT_CTR_NODE(level) (2 * (level))          // hits recorded at `level`
+#define RT_CTR_LINK(level) (2 * (level) - 1)      // secondary rays to trace at `level` (level >= 1)
+enum { RT_C_TOTAL = 2 * RT_MAX_LEVELS };
 // stats[] slots
 // *_REF = what the reference would trace: without glossy perturbation it re-traces gr_samples identical reflection
 // rays per hit, and with them their whole subtrees; every ray carries that multiplicity.
 enum { RT_S_PRIMARY = 0, RT_S_SHADOW, RT_S_REFLECT, RT_S_REFRACT, RT_S_NODES, RT_S_SHADOW_REF, RT_S_REFLECT_REF, RT_S_REFRACT_REF,
        RT_S_ERR = 8,               // non-zero when a capacity was exceeded during the frame
        RT_S_TOTAL = 16 };
+
+// 16-byte words the kernels copy into LDS when DevScene::lds_prims is set
+#define RT_LDS_PRIM_MAX_WORDS 384
+static inline int rt_lds_prim_words(const DevScene& sc) {
+    return sc.n_verts + 3 * (sc.fileset.n_planes + sc.leafset.n_planes) + 6 * (sc.fileset.n_cubes + sc.leafset.n_cubes) +
+           2 * (sc.fileset.n_spheres + sc.leafset.n_spheres) + 3 * (sc.fileset.n_planes + sc.fileset.n_cubes + sc.fileset.n_spheres);
+}
 
 // kernel launchers (rt_kernels.hip)
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);

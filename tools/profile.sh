@@ -12,5 +12,6 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OU
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $ARGS > "$OUT/pmc_fetch.log" 2>&1 || { echo "fetch pass failed"; tail -5 "$OUT/pmc_fetch.log"; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $ARGS > "$OUT/pmc_write.log" 2>&1 || { echo "write pass failed"; tail -5 "$OUT/pmc_write.log"; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $ARGS > "$OUT/pmc_sq.log" 2>&1 || { echo "sq pass failed"; tail -5 "$OUT/pmc_sq.log"; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM --output-format csv -d "$OUT/pmc_sq2" -- python3 bench.py $ARGS > "$OUT/pmc_sq2.log" 2>&1 || { echo "sq2 pass failed"; tail -5 "$OUT/pmc_sq2.log"; exit 1; }
 python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

@@ -33,7 +33,7 @@ for f in find("trace/**/*kernel_stats.csv"):
 
 traffic = {}
 print("\n== counters (sum over dispatches of each kernel; per-dispatch average in brackets) ==")
-for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     for f in find(f"{d}/**/*counter_collection.csv"):
         agg = defaultdict(lambda: defaultdict(float)); calls = defaultdict(set)
         for row in csv.DictReader(open(f)):
