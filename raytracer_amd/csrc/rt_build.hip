@@ -56,8 +56,11 @@ DEVI unsigned item_box(const DevPrimSet& S, const BuildGroup& g, int k, double s
     if (k < g.pn) {
         const int idx = g.p0 + k;
         const float4 w0 = S.planes[3 * (size_t)idx], w1 = S.planes[3 * (size_t)idx + 1];
-        const int first = f2i(w0.w), nv = f2i(w1.w) & 0xffff;
-        for (int v = 0; v < nv; ++v) { float4 p = S.verts[first + v]; db_add(b, p.x, p.y, p.z); }
+        const int first = f2i(w0.w), nv = f2i(w1.w) & 0xffff, drop = f2i(w1.w) >> 16;
+        for (int v = 0; v < nv; ++v) {                        // vertices are stored projected: (kept, kept, dropped)
+            float4 p = S.verts[first + v];
+            if (drop == 0) db_add(b, p.z, p.x, p.y); else if (drop == 1) db_add(b, p.x, p.z, p.y); else db_add(b, p.x, p.y, p.z);
+        }
         db_grow(b);
         return (unsigned)idx;
     }

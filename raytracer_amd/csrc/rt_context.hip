@@ -375,6 +375,19 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
         return true;
     };
 
+    // every plane owns its vertex range (each range is re-ordered and re-laid out in place below)
+    {
+        std::vector<char> claimed((size_t)sc->n_plane_verts, 0);
+        for (int i = 0; i < np; ++i) {
+            const rt_plane& p = sc->planes[i];
+            if (p.n_verts < 3 || p.n_verts > 0xffff || p.first_vert < 0 || p.first_vert + p.n_verts > sc->n_plane_verts)
+                return c->fail(RT_ERR_ARG, "plane %d: vertex range out of bounds", i);
+            for (int k = 0; k < p.n_verts; ++k) {
+                if (claimed[(size_t)p.first_vert + k]) return c->fail(RT_ERR_ARG, "plane %d: vertex range overlaps another plane's", i);
+                claimed[(size_t)p.first_vert + k] = 1;
+            }
+        }
+    }
     // planes: winding-sorted vertices, projection axis, texture axes
     c->h_verts_sorted.assign((size_t)sc->n_plane_verts, f4(0, 0, 0, 0));
     c->h_file_planes.assign((size_t)np * 3, f4(0, 0, 0, 0));
@@ -406,6 +419,13 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
             plane_uv[i * 3 + 1] = f4(vs[0], vs[1], vs[2], vl);
             plane_uv[i * 3 + 2] = f4(s0.x, s0.y, s0.z, 0.0f);
             put_mat((int)i, p.mat);
+            // the device tests the polygon in the projection that drops the dominant normal axis (plane.cpp:207-216):
+            // store every vertex as (kept, kept, dropped)
+            const int drop = drop_axis(p.normal);
+            for (int k = 0; k < p.n_verts; ++k) {
+                float4& q = c->h_verts_sorted[(size_t)p.first_vert + k];
+                if (drop == 0) q = f4(q.y, q.z, q.x, 0.0f); else if (drop == 1) q = f4(q.x, q.z, q.y, 0.0f);
+            }
         }
     });
     if (bad_plane >= 0) return c->fail(RT_ERR_ARG, "plane %d: vertex range out of bounds", bad_plane.load());

@@ -54,7 +54,8 @@ DEVI float powf_ref(float x, float y) { return (float)pow((double)x, (double)y);
 
 struct Ray { V3 o, d; float time; };
 
-// Philox-4x32 counter-based generator (7 rounds, the shortest variant that passes BigCrush):
+// Philox-4x32 counter-based generator (7 rounds, the shortest variant that passes BigCrush), for the per-pixel
+// draws (anti-aliasing jitter, lens, time) and the glossy cone:
 // value = f(counter, key), no state, any lane can draw any number.
 DEVI uint4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
@@ -66,6 +67,16 @@ DEVI uint4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     return make_uint4(c0, c1, c2, c3);
+}
+// Three decorrelated 32-bit values from a three-word counter: the PCG3D hash (Jarzynski and Olano, "Hash Functions
+// for GPU Rendering", JCGT 9(3), 2020), a fifth of Philox's integer work.  Used where one draw per ray is needed
+// and the count is large (the light-ball samples); the first word is a path id that is already a hash.
+DEVI uint3 pcg3d(uint32_t x, uint32_t y, uint32_t z) {
+    x = x * 1664525u + 1013904223u; y = y * 1664525u + 1013904223u; z = z * 1664525u + 1013904223u;
+    x += y * z; y += z * x; z += x * y;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16;
+    x += y * z; y += z * x; z += x * y;
+    return make_uint3(x, y, z);
 }
 DEVI float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }               // [0,1)
 DEVI uint32_t mix32(uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
@@ -249,11 +260,10 @@ DEVI bool plane_test(const float4* __restrict__ rec, const float4* __restrict__ 
     float Px = (drop == 0) ? ip.y : ip.x;
     float Py = (drop == 2) ? ip.y : ip.z;
     bool inside = false;
-    float4 vj = verts[first + n - 1];
+    float4 vj = verts[first + n - 1];                                    // vertices are stored already projected
     for (int i = 0; i < n; ++i) {
         float4 vi = verts[first + i];
-        float Pix = (drop == 0) ? vi.y : vi.x, Piy = (drop == 2) ? vi.y : vi.z;
-        float Pjx = (drop == 0) ? vj.y : vj.x, Pjy = (drop == 2) ? vj.y : vj.z;
+        float Pix = vi.x, Piy = vi.y, Pjx = vj.x, Pjy = vj.y;
         vj = vi;
         if (fabsf(Pjy - Piy) < 1e-8f) continue;
         if ((Piy > Py) != (Pjy > Py)) {
@@ -841,7 +851,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene s
                 unblocked = !trace<true, SUB>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
             } else {
                 uint32_t path = (uint32_t)f2i(w.n_c[node].z);
-                uint4 q = philox(path, (uint32_t)l, (uint32_t)j, STREAM_SHADOW, f.seed, 0x52541u);
+                uint3 q = pcg3d(path ^ (f.seed * 0x9E3779B1u), (uint32_t)l ^ 0x52541u, (uint32_t)j);
                 V3 jit = unit_sphere(u01(q.x), u01(q.y), u01(q.z)) * f.light_radius;
                 V3 lp = mk(lt.x + jit.x, lt.y + jit.y, lt.z + jit.z);
                 V3 h2l = lp - p;

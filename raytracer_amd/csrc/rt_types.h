@@ -22,7 +22,8 @@
 //   plane  : 3 words  w0 = (n.x, n.y, n.z, bits first_vert)
 //                     w1 = (v0.x, v0.y, v0.z, bits n_verts | drop_axis << 16)   v0 = vertex the plane offset uses
 //                     w2 = (bits gid, 0, 0, 0)
-//   vertex : 1 word   (x, y, z, 0)  winding-sorted polygon vertices
+//   vertex : 1 word   (p, q, d, 0)  winding-sorted polygon vertices in the plane's 2D projection: d = the dropped
+//                     coordinate, (p, q) = the other two in x, y, z order (drop x: y, z; drop y: x, z; drop z: x, y)
 //   cube   : 6 words  w0 = (start.xyz, scale)  w1 = (end.xyz, 1/scale)
 //                     w2 = (cos rx, sin rx, cos ry, sin ry)  w3 = (cos rz, sin rz, bits gid, 0)
 //                     w4 = (cos -rz, sin -rz, cos -ry, sin -ry)  w5 = (cos -rx, sin -rx, 0, 0)
