@@ -200,14 +200,21 @@ def main():
 
     staged = args.backend == "gloo"      # rehearsal path: gloo moves host tensors
 
+    # N > 1 over RCCL: frames are pipelined.  Frame k is rendered on the render stream into one of two blocks; its
+    # gather runs on the communicator's stream and rank 0 re-orders it on a third stream, both beside the kernels of
+    # frame k + 1.  Buffers are reused every other frame behind events; the timed region ends with a device-wide
+    # synchronisation, so every frame's image has reached rank 0 inside it.
+    pipelined = world > 1 and not staged
+    pipe = rdist.FramePipeline(r, cfg, rank, world, dev, stream) if pipelined else None
+
     def step():
+        if pipelined:
+            pipe.step()
+            return None
         r.render_device(cfg, block.data_ptr())
         if world > 1:
-            if staged:
-                g = rdist.gather_blocks(block.cpu(), 0)
-                gathered = g.to(dev) if rank == 0 else None
-            else:
-                gathered = rdist.gather_blocks(block, 0)
+            g = rdist.gather_blocks(block.cpu(), 0)
+            gathered = g.to(dev) if rank == 0 else None
             if rank == 0:
                 r.assemble(gathered.data_ptr(), world, image.data_ptr())
                 keep.append(gathered)            # the assemble kernel is only enqueued: keep its input alive
@@ -254,7 +261,7 @@ def main():
     if rank == 0:
         ms_per_step = 1000.0 * elapsed / args.steps
         # rank-0 sanity: the frame is not black and (N=1) is the row-major image itself
-        final = (image if world > 1 else block).cpu().numpy()
+        final = ((pipe.image if pipelined else image) if world > 1 else block).cpu().numpy()
         lit = float((final.reshape(-1, 3).sum(axis=1) > 0).mean())
         line = {
             "metric": "rays/sec (all ray types), 1080p scene.json" if args.workload == "config2" else f"rays/sec (all ray types), {args.workload}",

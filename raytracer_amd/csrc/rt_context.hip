@@ -307,8 +307,7 @@ void rt_destroy(rt_ctx* c) {
 
 int rt_set_stream(rt_ctx* c, void* hip_stream) {
     if (!c) return RT_ERR_ARG;
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
-    c->drop_graphs();
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;   // recorded frames are keyed by stream and stay valid
     return RT_OK;
 }
 

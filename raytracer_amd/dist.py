@@ -41,6 +41,14 @@ def gather_blocks(block: torch.Tensor, dst: int = 0) -> torch.Tensor | None:
     return None
 
 
+def gather_blocks_async(block: torch.Tensor, out: torch.Tensor | None, dst: int = 0):
+    """Starts the gather of `block` into the preallocated rank-major `out` (only on `dst`; None elsewhere) and
+    returns the work handle: `handle.wait()` makes the CURRENT stream wait for the transfer (it does not block the
+    host), so a frame's gather can run beside the next frame's kernels."""
+    world = dist.get_world_size()
+    return dist.gather(block, list(out.chunk(world)) if dist.get_rank() == dst else None, dst=dst, async_op=True)
+
+
 def broadcast_bytes(data: bytes | None, src: int = 0, device: torch.device | None = None) -> bytes:
     """Scene text / flags travel from rank 0 once per frame set (the scene and BVH broadcast of the design)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -84,3 +92,44 @@ def broadcast_scene(loaded, with_bvh: bool, src: int = 0, device: torch.device |
     blob = api.pack_scene(loaded, with_bvh) if dist.get_rank() == src else None
     blob = broadcast_array(blob, src, device)
     return loaded if dist.get_rank() == src else api.PackedScene(blob)
+
+
+class FramePipeline:
+    """Frames of a multi-rank run, pipelined: frame k is rendered on `render_stream` into one of two blocks; its gather
+    runs beside the kernels of frame k + 1 (on the communicator's stream) and rank 0 re-orders it into the row-major
+    image on a third stream.  Buffers are reused every other frame behind the gather handle and an event.
+    `start_gather(block, out_or_None)` returns a handle whose wait() makes the current stream wait for the transfer
+    (gather_blocks_async over RCCL; tests substitute device copies)."""
+
+    def __init__(self, renderer, cfg, rank: int, world: int, device, render_stream, start_gather=gather_blocks_async):
+        self.r, self.cfg, self.rank, self.world = renderer, cfg, rank, world
+        self.stream = render_stream
+        self.start_gather = start_gather
+        n = renderer.out_bytes()
+        self.blocks = [torch.empty(n, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.gathered = [torch.empty(world * n, dtype=torch.uint8, device=device) if rank == 0 else None for _ in range(2)]
+        self.image = torch.empty(renderer.width * renderer.height * 3, dtype=torch.uint8, device=device) if rank == 0 else None
+        self.asm_stream = torch.cuda.Stream(device) if rank == 0 else None
+        self.pending = [None, None]
+        self.asm_done = [None, None]
+        self.frame = 0
+
+    def step(self):
+        b = self.frame % 2
+        self.frame += 1
+        with torch.cuda.stream(self.stream):
+            if self.pending[b] is not None:
+                self.pending[b].wait()                          # the gather that last read blocks[b], two frames ago
+            if self.asm_done[b] is not None:
+                self.stream.wait_event(self.asm_done[b])        # the re-ordering that last read gathered[b]
+            self.r.set_stream(self.stream.cuda_stream)
+            self.r.render_device(self.cfg, self.blocks[b].data_ptr())
+            self.pending[b] = self.start_gather(self.blocks[b], self.gathered[b])
+        if self.rank == 0:
+            with torch.cuda.stream(self.asm_stream):
+                self.pending[b].wait()
+                self.r.set_stream(self.asm_stream.cuda_stream)
+                self.r.assemble(self.gathered[b].data_ptr(), self.world, self.image.data_ptr())
+                self.r.set_stream(self.stream.cuda_stream)
+                ev = torch.cuda.Event(); ev.record(self.asm_stream)
+                self.asm_done[b] = ev

@@ -305,3 +305,65 @@ def test_shadow_overlap_equals_serial_launches():
     assert base.max() > 0
     for key, img in imgs.items():
         assert np.array_equal(img, base), f"overlap, graphs = {key} differs from the serial frame"
+
+
+def test_pipelined_frames_two_shards_in_one_process():
+    """The multi-rank frame pipeline (render k+1 beside gather k and the re-ordering of k, double-buffered) with two
+    shard contexts on one GPU and device copies standing in for the RCCL gather.  Every frame uses another seed, so a
+    block or gather buffer that is reused too early shows up as a wrong final image."""
+    from raytracer_amd import dist as rdist
+    import copy
+    text = cases.reference_scene(640, 360)
+    flags = ["-rd", "2", "-grs", "1", "-ss", "-sss", "4"]
+    cfg, _ = api.parse_args(flags)
+    ls = api.LoadedScene(text, cfg)
+    dev = torch.device("cuda", 0)
+    world = 2
+    rs = []
+    for k in range(world):
+        r = api.Renderer(0); r.upload(ls); r.set_shard(k, world); rs.append(r)
+    n = rs[0].out_bytes()
+    comm = torch.cuda.Stream(dev)
+    mailbox, handles = {}, {}
+
+    class Handle:
+        ev = None
+        def wait(self):
+            if self.ev is not None:
+                torch.cuda.current_stream().wait_event(self.ev)
+
+    def make_gather(rank):
+        count = [0]
+        def start(block, out):
+            k = count[0]; count[0] += 1
+            h = handles.setdefault(k, Handle())
+            ready = torch.cuda.Event(); ready.record(torch.cuda.current_stream())
+            mailbox.setdefault(k, {})[rank] = (block, ready)
+            if rank == 0:                                   # rank 1 has stepped first in every frame
+                with torch.cuda.stream(comm):
+                    for q in range(world):
+                        blk, ev = mailbox[k][q]
+                        comm.wait_event(ev)
+                        out[q * n:(q + 1) * n].copy_(blk, non_blocking=True)
+                    h.ev = torch.cuda.Event(); h.ev.record(comm)
+            return h
+        return start
+
+    pipes = [rdist.FramePipeline(rs[k], copy.copy(cfg), k, world, dev, torch.cuda.Stream(dev), make_gather(k)) for k in range(world)]
+    frames = 7
+    for frame in range(frames):
+        for k in (1, 0):
+            pipes[k].cfg.seed = 100 + frame
+            pipes[k].step()
+    torch.cuda.synchronize()
+    got = pipes[0].image.cpu().numpy().reshape(360, 640, 3)
+    single = api.Renderer(0); single.upload(ls)
+    last = copy.copy(cfg); last.seed = 100 + frames - 1
+    want, _ = single.render(last)
+    prev = copy.copy(cfg); prev.seed = 100 + frames - 2
+    other, _ = single.render(prev)
+    assert not np.array_equal(want, other)
+    assert np.array_equal(got, want)
+    for r in rs + [single]:
+        r.close()
+    ls.close()
