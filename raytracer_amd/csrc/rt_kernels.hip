@@ -372,17 +372,18 @@ DEVI bool test_prims(const DevPrimSet& S, const Ray& r, bool mb, int p0, int pn,
 // An interior node holds both children's boxes: (minL, refL) (maxL, cntL) (minR, refR) (maxR, cntR); ref >= 0 is an
 // interior node, ref < 0 a run of cnt entries starting at ~ref.  entry = class << 30 | index in the set.
 // ---------------------------------------------------------------------------------------------------------
-struct SubRay { V3 om, op, rcp; float lo[3], hi[3]; bool par[3]; };
+struct SubRay { V3 om, op, rcp; };
 
-DEVI void sub_child(const SubRay& q, const Ray& r, float4 mn, float4 mx, float& tn, float& tf) {
+// Entry and exit parameter of the ray against a box enlarged by the per-ray pad, with slack for the rounding of
+// the reciprocal-multiply.  A direction component too small to divide by carries the finite stand-in reciprocal
+// 1e30 (see sub_trace): the two products then have the signs of (min - origin) and (max - origin), so an origin
+// inside the padded slab yields (-huge, +huge), no constraint, and one outside yields two huge values of one sign,
+// a certain miss.
+DEVI void sub_child(const SubRay& q, float4 mn, float4 mx, float& tn, float& tf) {
     float a0 = (mn.x - q.op.x) * q.rcp.x, b0 = (mx.x - q.om.x) * q.rcp.x;
     float a1 = (mn.y - q.op.y) * q.rcp.y, b1 = (mx.y - q.om.y) * q.rcp.y;
     float a2 = (mn.z - q.op.z) * q.rcp.z, b2 = (mx.z - q.om.z) * q.rcp.z;
     float n0 = fminf(a0, b0), f0 = fmaxf(a0, b0), n1 = fminf(a1, b1), f1 = fmaxf(a1, b1), n2 = fminf(a2, b2), f2 = fmaxf(a2, b2);
-    // a direction component too small to divide by: inside the padded slab -> no constraint, outside -> miss
-    if (q.par[0]) { bool in = !(r.o.x < mn.x - (q.op.x - r.o.x)) && !(r.o.x > mx.x + (q.op.x - r.o.x)); n0 = in ? -INFINITY : INFINITY; f0 = in ? INFINITY : -INFINITY; }
-    if (q.par[1]) { bool in = !(r.o.y < mn.y - (q.op.y - r.o.y)) && !(r.o.y > mx.y + (q.op.y - r.o.y)); n1 = in ? -INFINITY : INFINITY; f1 = in ? INFINITY : -INFINITY; }
-    if (q.par[2]) { bool in = !(r.o.z < mn.z - (q.op.z - r.o.z)) && !(r.o.z > mx.z + (q.op.z - r.o.z)); n2 = in ? -INFINITY : INFINITY; f2 = in ? INFINITY : -INFINITY; }
     tn = fmaxf(fmaxf(n0, n1), n2);
     tf = fminf(fminf(f0, f1), f2);
     float E = 2e-6f * fmaxf(fabsf(tn), fabsf(tf));
@@ -399,8 +400,9 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, const Ray
         float pad = 2e-5f * (__builtin_amdgcn_sqrtf(dot(dc, dc)) + sc.radius) + 1e-6f * sc.radius;
         if (!(pad >= 0.0f)) pad = INFINITY;          // NaN origin: nothing may be skipped
         q.om = mk(r.o.x - pad, r.o.y - pad, r.o.z - pad); q.op = mk(r.o.x + pad, r.o.y + pad, r.o.z + pad);
-        q.par[0] = !(fabsf(r.d.x) > 1e-12f); q.par[1] = !(fabsf(r.d.y) > 1e-12f); q.par[2] = !(fabsf(r.d.z) > 1e-12f);
-        q.rcp = mk(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
+        // zero, denormal-small or NaN components get a huge finite reciprocal instead of inf / NaN
+        q.rcp = mk(fabsf(r.d.x) > 1e-12f ? __builtin_amdgcn_rcpf(r.d.x) : 1e30f, fabsf(r.d.y) > 1e-12f ? __builtin_amdgcn_rcpf(r.d.y) : 1e30f,
+                   fabsf(r.d.z) > 1e-12f ? __builtin_amdgcn_rcpf(r.d.z) : 1e30f);
     }
     float best_t = leaf_rule ? INFINITY : FLT_MAX;
     unsigned best_key = 0u; bool has = false;
@@ -409,8 +411,8 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, const Ray
         const float4* __restrict__ nd = sc.sub_nodes + 4 * (size_t)node;
         float4 lmn = nd[0], lmx = nd[1], rmn = nd[2], rmx = nd[3];
         float ltn, ltf, rtn, rtf;
-        sub_child(q, r, lmn, lmx, ltn, ltf);
-        sub_child(q, r, rmn, rmx, rtn, rtf);
+        sub_child(q, lmn, lmx, ltn, ltf);
+        sub_child(q, rmn, rmx, rtn, rtf);
         // skip only on a certain miss; any NaN makes the comparisons false and the child is visited
         bool goL = !(ltn > ltf) && !(ltf < 0.0f) && !(ltn > best_t);
         bool goR = !(rtn > rtf) && !(rtf < 0.0f) && !(rtn > best_t);
