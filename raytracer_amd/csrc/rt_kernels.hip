@@ -391,19 +391,23 @@ DEVI void sub_child(const SubRay& q, float4 mn, float4 mx, float& tn, float& tf)
     tn -= E; tf += E;
 }
 
-template <bool ANY>
-DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, const Ray& r, bool mb, bool leaf_rule,
-                    int* __restrict__ stack, Best& best) {
+// Per-ray constants of the second-level walk: origin -/+ the pad that covers what a primitive test may report
+// outside the primitive's true bounds, and the reciprocal direction.  Computed once per ray, not once per group.
+DEVI SubRay make_sub_ray(const DevScene& sc, const Ray& r) {
     SubRay q;
-    {
-        V3 dc = r.o - mk(sc.center[0], sc.center[1], sc.center[2]);
-        float pad = 2e-5f * (__builtin_amdgcn_sqrtf(dot(dc, dc)) + sc.radius) + 1e-6f * sc.radius;
-        if (!(pad >= 0.0f)) pad = INFINITY;          // NaN origin: nothing may be skipped
-        q.om = mk(r.o.x - pad, r.o.y - pad, r.o.z - pad); q.op = mk(r.o.x + pad, r.o.y + pad, r.o.z + pad);
-        // zero, denormal-small or NaN components get a huge finite reciprocal instead of inf / NaN
-        q.rcp = mk(fabsf(r.d.x) > 1e-12f ? __builtin_amdgcn_rcpf(r.d.x) : 1e30f, fabsf(r.d.y) > 1e-12f ? __builtin_amdgcn_rcpf(r.d.y) : 1e30f,
-                   fabsf(r.d.z) > 1e-12f ? __builtin_amdgcn_rcpf(r.d.z) : 1e30f);
-    }
+    V3 dc = r.o - mk(sc.center[0], sc.center[1], sc.center[2]);
+    float pad = 2e-5f * (__builtin_amdgcn_sqrtf(dot(dc, dc)) + sc.radius) + 1e-6f * sc.radius;
+    if (!(pad >= 0.0f)) pad = INFINITY;          // NaN origin: nothing may be skipped
+    q.om = mk(r.o.x - pad, r.o.y - pad, r.o.z - pad); q.op = mk(r.o.x + pad, r.o.y + pad, r.o.z + pad);
+    // zero, denormal-small or NaN components get a huge finite reciprocal instead of inf / NaN
+    q.rcp = mk(fabsf(r.d.x) > 1e-12f ? __builtin_amdgcn_rcpf(r.d.x) : 1e30f, fabsf(r.d.y) > 1e-12f ? __builtin_amdgcn_rcpf(r.d.y) : 1e30f,
+               fabsf(r.d.z) > 1e-12f ? __builtin_amdgcn_rcpf(r.d.z) : 1e30f);
+    return q;
+}
+
+template <bool ANY>
+DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, const Ray& r, const SubRay& q, bool mb, bool leaf_rule,
+                    int* __restrict__ stack, Best& best) {
     float best_t = leaf_rule ? INFINITY : FLT_MAX;
     unsigned best_key = 0u; bool has = false;
     int sp = 0, node = root;
@@ -455,9 +459,9 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, const Ray
 // Closest hit of a group of primitives: through its second-level hierarchy when it has one, else one by one.
 // SUB = the scene has at least one second-level hierarchy (kernels for small scenes are compiled without that code).
 template <bool ANY, bool SUB>
-DEVI bool test_group(const DevScene& sc, const DevPrimSet& S, const Ray& r, bool mb, int p0, int pn, int c0, int cn, int s0, int sn,
+DEVI bool test_group(const DevScene& sc, const DevPrimSet& S, const Ray& r, const SubRay& q, bool mb, int p0, int pn, int c0, int cn, int s0, int sn,
                      int sub_root, bool leaf_rule, int* __restrict__ stack, Best& best) {
-    if (SUB && sub_root >= 0) return sub_trace<ANY>(sc, S, sub_root, r, mb, leaf_rule, stack, best);
+    if (SUB && sub_root >= 0) return sub_trace<ANY>(sc, S, sub_root, r, q, mb, leaf_rule, stack, best);
     return test_prims<ANY>(S, r, mb, p0, pn, c0, cn, s0, sn, leaf_rule, best);
 }
 
@@ -470,6 +474,8 @@ template <bool ANY, bool SUB>
 DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict__ nodes, const int4* __restrict__ leaves,
                 int* __restrict__ stack, const Ray& r, bool with_fallback, Best& best) {
     const bool mb = f.motion_blur != 0;
+    SubRay q; q.om = q.op = q.rcp = mk(0.0f, 0.0f, 0.0f);
+    if (SUB) q = make_sub_ray(sc, r);
     if (f.use_bvh) {
         int i = 0;
         const int n = sc.n_nodes;
@@ -484,16 +490,16 @@ DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict_
             ++i;
             if (leaf >= 0) {
                 int4 l0 = leaves[2 * leaf], l1 = leaves[2 * leaf + 1];
-                if (test_group<ANY, SUB>(sc, sc.leafset, r, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, true, stack, best)) { best.fileset = 0; return true; }
+                if (test_group<ANY, SUB>(sc, sc.leafset, r, q, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, true, stack, best)) { best.fileset = 0; return true; }
             }
         }
         if (!with_fallback) return false;
         best.fileset = 1;
-        return test_group<false, SUB>(sc, sc.fileset, r, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
+        return test_group<false, SUB>(sc, sc.fileset, r, q, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
                                  sc.file_sub_root, false, stack, best);
     }
     best.fileset = 1;
-    return test_group<ANY, SUB>(sc, sc.fileset, r, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
+    return test_group<ANY, SUB>(sc, sc.fileset, r, q, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
                            sc.file_sub_root, false, stack, best);
 }
 
