@@ -54,23 +54,10 @@ DEVI float powf_ref(float x, float y) { return (float)pow((double)x, (double)y);
 
 struct Ray { V3 o, d; float time; };
 
-// Philox-4x32 counter-based generator (7 rounds, the shortest variant that passes BigCrush), for the per-pixel
-// draws (anti-aliasing jitter, lens, time) and the glossy cone:
-// value = f(counter, key), no state, any lane can draw any number.
-DEVI uint4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-#pragma unroll
-    for (int r = 0; r < 7; ++r) {
-        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0, hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return make_uint4(c0, c1, c2, c3);
-}
-// Three decorrelated 32-bit values from a three-word counter: the PCG3D hash (Jarzynski and Olano, "Hash Functions
-// for GPU Rendering", JCGT 9(3), 2020), a fifth of Philox's integer work.  Used where one draw per ray is needed
-// and the count is large (the light-ball samples); the first word is a path id that is already a hash.
+// Counter-based random numbers: three decorrelated 32-bit values from a three-word counter, no state, any lane can
+// draw any number.  This is the PCG3D hash (Jarzynski and Olano, "Hash Functions for GPU Rendering", JCGT 9(3), 2020):
+// about twenty integer operations per call.  Counters are (pixel or path id mixed with the seed, sample index,
+// stream), so a value is a pure function of what it is drawn for, whatever the rank count, chunking or scheduling.
 DEVI uint3 pcg3d(uint32_t x, uint32_t y, uint32_t z) {
     x = x * 1664525u + 1013904223u; y = y * 1664525u + 1013904223u; z = z * 1664525u + 1013904223u;
     x += y * z; y += z * x; z += x * y;
@@ -581,7 +568,7 @@ DEVI bool generate_primary(const DevFrame& f, int i, Ray& r, uint32_t& path, int
     int s_mb = s % f.mb_n, s_dof = (s / f.mb_n) % f.dof_n, s_aa = s / (f.mb_n * f.dof_n);
     float u = (float)x, v = (float)y;
     if (f.anti_aliasing) {                                              // raytracer.cpp:123-127
-        uint4 q = philox(pixel, (uint32_t)s_aa, 0u, STREAM_AA, f.seed, 0x52541u);
+        uint3 q = pcg3d(pixel ^ (f.seed * 0x9E3779B1u), (uint32_t)s_aa, STREAM_AA);
         u = (float)x + u01(q.x);
         v = (float)y + u01(q.y);
     }
@@ -599,7 +586,7 @@ DEVI bool generate_primary(const DevFrame& f, int i, Ray& r, uint32_t& path, int
     d = mk(-d.x, -d.y, -d.z);
     V3 o = mk(f.cam_loc[0], f.cam_loc[1], f.cam_loc[2]);
     if (f.lens_radius > 0.0f) {                                         // camera.cpp:181-196, 286-312
-        uint4 q = philox(pixel, (uint32_t)(s_aa * f.dof_n + s_dof), 0u, STREAM_DOF, f.seed, 0x52541u);
+        uint3 q = pcg3d(pixel ^ (f.seed * 0x9E3779B1u), (uint32_t)(s_aa * f.dof_n + s_dof), STREAM_DOF);
         float lx = 2.0f * u01(q.x) - 1.0f, ly = 2.0f * u01(q.y) - 1.0f;
         float sx = 0.0f, sy = 0.0f;
         if (!(lx == 0.0f && ly == 0.0f)) {
@@ -618,7 +605,7 @@ DEVI bool generate_primary(const DevFrame& f, int i, Ray& r, uint32_t& path, int
     }
     float time = 0.0f;
     if (f.motion_blur) {                                                // raytracer.cpp:141 (only read when -m is on)
-        uint4 q = philox(pixel, (uint32_t)s, 0u, STREAM_MB, f.seed, 0x52541u);
+        uint3 q = pcg3d(pixel ^ (f.seed * 0x9E3779B1u), (uint32_t)s, STREAM_MB);
         time = ((float)s_mb + u01(q.x)) / (float)f.mb_n;
     }
     r.o = o; r.d = d; r.time = time;
@@ -765,7 +752,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
                 V3 dir = rd;
                 uint32_t cpath = mix32(path * 0x9E3779B1u + (uint32_t)j + 1u);
                 if (glossy) {
-                    uint4 q = philox(path, (uint32_t)j, (uint32_t)level, STREAM_GLOSSY, f.seed, 0x52541u);
+                    uint3 q = pcg3d(path ^ (f.seed * 0x9E3779B1u), (uint32_t)j, (uint32_t)level * 16u + STREAM_GLOSSY);
                     dir = cone_direction(rd, gloss_angle, q.x, q.y);
                 }
                 V3 org = h.p + N * EPS;
@@ -859,7 +846,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene s
                 unblocked = !trace<true, SUB>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
             } else {
                 uint32_t path = (uint32_t)f2i(w.n_c[node].z);
-                uint3 q = pcg3d(path ^ (f.seed * 0x9E3779B1u), (uint32_t)l ^ 0x52541u, (uint32_t)j);
+                uint3 q = pcg3d(path ^ (f.seed * 0x9E3779B1u), (uint32_t)j, (uint32_t)l * 16u + STREAM_SHADOW);
                 V3 jit = unit_sphere(u01(q.x), u01(q.y), u01(q.z)) * f.light_radius;
                 V3 lp = mk(lt.x + jit.x, lt.y + jit.y, lt.z + jit.z);
                 V3 h2l = lp - p;
