@@ -898,8 +898,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     w.cap_nodes = (unsigned)cap_nodes;
     for (int d = 0; d <= D + 2 && d < RT_MAX_LEVELS; ++d) { w.node_off[d] = (int)node_off[(size_t)std::min(d, D + 1)]; w.link_off[d] = (int)link_off[(size_t)d]; }
 
-    RT_HIP(c, hipMemsetAsync(c->accum.p, 0, (size_t)n_slots * sizeof(float4), s));
-    if (want_stats_zero) RT_HIP(c, hipMemsetAsync(c->stats.p, 0, RT_S_TOTAL * sizeof(unsigned long long), s));
+    rt_launch_begin_frame(s, w, (int)n_slots, want_stats_zero);      // per-pixel sums, first batch's counters, statistics
 
     const int max_grid = 2048;       // 256 CUs x 8 workgroups: enough to fill the chip, grid-stride beyond that
     unsigned long long batches = 0;
@@ -916,7 +915,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         const int grid0 = std::max(1, std::min(max_grid, (count + RT_BLOCK - 1) / RT_BLOCK));
         for (int smp = 0; smp < S; ++smp) {
             f.sample = smp;
-            RT_HIP(c, hipMemsetAsync(c->ctr.p, 0, RT_C_TOTAL * sizeof(int), s));   // counters and level starts of the batch
+            if (batches > 0) RT_HIP(c, hipMemsetAsync(c->ctr.p, 0, RT_C_TOTAL * sizeof(int), s));   // counters of the batch
             if (!grouped) RT_HIP(c, hipMemsetAsync(c->shadow.p, 0, cap_nodes * (size_t)std::max(L, 1) * sizeof(float), s));
             for (int level = 0; level <= D; ++level) {
                 tm->begin(level == 0 ? ST_EXTEND_PRIMARY : ST_EXTEND_SECONDARY);

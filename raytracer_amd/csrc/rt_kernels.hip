@@ -1022,6 +1022,17 @@ __global__ void k_assemble(const unsigned char* __restrict__ tiles, int world, i
 
 } // namespace
 
+// Start of a frame: zero the per-pixel sums, the first batch's counters and (optionally) the ray statistics in one
+// launch instead of three fills.
+__global__ void k_begin_frame(float4* __restrict__ accum, int n_slots, int* __restrict__ ctr, unsigned long long* __restrict__ stats) {
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) accum[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < RT_C_TOTAL; i += blockDim.x) ctr[i] = 0;
+        if (stats) for (int i = threadIdx.x; i < RT_S_TOTAL; i += blockDim.x) stats[i] = 0ull;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
@@ -1058,6 +1069,11 @@ void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, cons
 
 void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, s, sc, f, w, level);
+}
+
+void rt_launch_begin_frame(hipStream_t s, const DevWork& w, int n_slots, bool zero_stats) {
+    int grid = (n_slots + RT_BLOCK - 1) / RT_BLOCK; if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_begin_frame, dim3(grid), dim3(RT_BLOCK), 0, s, w.accum, n_slots, w.ctr, zero_stats ? w.stats : (unsigned long long*)nullptr);
 }
 
 void rt_launch_finalize(hipStream_t s, const DevFrame& f, const DevWork& w, unsigned char* out, int tile_major, int n_slots, int samples) {

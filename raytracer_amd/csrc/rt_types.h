@@ -130,6 +130,7 @@ static inline int rt_lds_prim_words(const DevScene& sc) {
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);
 void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid);
 void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);
+void rt_launch_begin_frame(hipStream_t s, const DevWork& w, int n_slots, bool zero_stats);
 void rt_launch_finalize(hipStream_t s, const DevFrame& f, const DevWork& w, unsigned char* out, int tile_major, int n_slots, int samples);
 void rt_launch_assemble(hipStream_t s, const unsigned char* tiles, int world, int max_tiles, int tiles_x, int tiles_y,
                         int width, int height, unsigned char* out);
