@@ -171,7 +171,39 @@ def test_error_paths():
         r.render(bad)
     with pytest.raises(api.RtError):
         r.set_shard(3, 2)
+    # two planes may not share vertices: the library re-orders and re-lays-out each plane's vertex range in place
+    import ctypes as C
+    sc = api.Scene(); C.memmove(C.byref(sc), C.byref(ls.scene), C.sizeof(api.Scene))
+    planes = (api.Plane * 2)()
+    for k in range(2):
+        C.memmove(C.byref(planes[k]), C.byref(ls.scene.planes[0]), C.sizeof(api.Plane))
+    sc.planes = planes; sc.n_planes = 2
+    with pytest.raises(api.RtError) as e:
+        r._check(api.lib().rt_upload_scene(r._ctx, C.byref(sc)))
+    assert e.value.code == -1 and "overlaps" in str(e.value)
+    with pytest.raises(api.RtError):
+        r.render(cfg_u)                                 # the failed upload left no scene behind
     r.close(); ls.close()
+
+
+@pytest.mark.parametrize("scene,flags", [("ref", ["-rd", "3", "-grs", "1", "-ss", "-sss", "4", "-t"]), ("glass_tex", ["-rd", "2", "-grs", "1", "-t", "-u"]),
+                                         ("glass", ["-m", "-mbs", "1", "-rd", "2", "-grs", "1"])])
+def test_lds_resident_primitive_records_change_nothing(scene, flags, textures_dir):
+    """Tiny scenes keep their primitive records and materials in LDS (shadow kernel by default, the extend kernels as an
+    option): identical frames and ray counts with the records in global memory."""
+    cfg, _ = api.parse_args(flags)
+    cfg.seed = 5
+    ls = api.LoadedScene(cases.SCENES[scene](), cfg, textures_dir)
+    got = []
+    for mode in (0, 1, 2):
+        r = api.Renderer(0); r.set_option("lds_prims", mode); r.upload(ls, with_bvh=bool(cfg.bvh))
+        img, st = r.render(cfg)
+        got.append((img, (st.shadow_rays, st.reflection_rays, st.refraction_rays, st.nodes_shaded)))
+        r.close()
+    ls.close()
+    assert got[0][0].max() > 0
+    for img, counts in got[1:]:
+        assert np.array_equal(img, got[0][0]) and counts == got[0][1]
 
 
 # ---- large scenes: the second-level hierarchy ----------------------------------------------------------------
