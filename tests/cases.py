@@ -28,8 +28,21 @@ def reference_scene(w: int = 1920, h: int = 1080) -> str:
     return with_resolution((GOLDEN / "scene.json").read_text(), w, h)
 
 
+def blend_scene(name: str, w: int, h: int) -> str:
+    """A scene of the reference that exists only as Blend/<name>.blend, exported to scene.json text by
+    raytracer_amd.blend_export (tests/golden/make_scenes.py) and committed as a data fixture."""
+    return with_resolution((GOLDEN / "scenes" / f"{name}.json").read_text(), w, h)
+
+
 SCENES = {
     "ref": lambda: reference_scene(240, 135),
+    # the reference's own Blender scenes
+    "bvh5": lambda: blend_scene("bvh_vs_unaccel_5", 240, 135),
+    "texmap1": lambda: blend_scene("texture_mapping1", 200, 112),
+    "cube_mb": lambda: blend_scene("cube_mb", 160, 90),
+    "blinn": lambda: blend_scene("blinn_phong_test", 200, 112),
+    "test1": lambda: blend_scene("Test1", 200, 112),
+    "test2": lambda: blend_scene("Test2", 160, 90),
     "ref120": lambda: reference_scene(120, 68),
     "glass": lambda: sg.glass_scene((200, 112)),
     "glass_tex": lambda: sg.glass_scene((200, 112), True),
@@ -65,6 +78,16 @@ DETERMINISTIC = [
     ("rand2k", []),
     ("rand2k", ["-u"]),
     ("rand2k", ["-rd", "2", "-grs", "1"]),
+    ("bvh5", []),
+    ("bvh5", ["-u"]),
+    ("bvh5", ["-rd", "3", "-grs", "1"]),
+    ("texmap1", ["-t"]),
+    ("texmap1", ["-t", "-u", "-r", "-grs", "1"]),
+    ("cube_mb", []),
+    ("blinn", ["-r", "-grs", "1"]),
+    ("test1", ["-rd", "2", "-grs", "1"]),
+    ("test2", []),
+    ("test2", ["-u"]),
 ]
 
 # Stochastic flag sets: judged by PSNR >= 40 dB between two high-sample renders (the golden one is the reference's).
@@ -79,6 +102,9 @@ STOCHASTIC = [
     ("rand300m", ["-m", "-mbs", "128", "-r", "-grs", "1"]),
     # the flag set of the 4K multi-sample configuration (4096 samples per pixel) on a small film
     ("ref120", ["-aa", "-aas", "16", "-gr", "-grs", "16", "-dof", "-dofs", "16", "-m", "-mbs", "16"]),
+    # the reference's motion-blur scene and its 18-object scene with soft shadows
+    ("cube_mb", ["-m", "-mbs", "256"]),
+    ("bvh5", ["-ss", "-sss", "256"]),
 ]
 
 

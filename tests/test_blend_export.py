@@ -1,0 +1,76 @@
+"""raytracer_amd.blend_export: the reference's Blender exporter (Blend/Export.py) evaluated without Blender."""
+import json
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import cases
+from raytracer_amd import api, blend_export as be
+
+REF = Path("/root/reference")
+have_ref = (REF / "Blend" / "dof.blend").exists()
+SCENES = cases.GOLDEN / "scenes"
+
+
+@pytest.mark.skipif(not have_ref, reason="/root/reference is not mounted here")
+def test_dof_blend_reproduces_the_shipped_scene_json():
+    """The only (.blend, scene.json) pair the reference ships: the exported text must be the file, byte for byte
+    (object order, float32 values widened, double-precision shininess, Blender's rotation and vector arithmetic)."""
+    assert be.export_scene_json(str(REF / "Blend" / "dof.blend")) == (REF / "ASCII" / "scene.json").read_text()
+
+
+@pytest.mark.skipif(not have_ref, reason="/root/reference is not mounted here")
+def test_every_blend_file_exports_to_its_committed_fixture():
+    blends = sorted((REF / "Blend").glob("*.blend"))
+    assert len(blends) >= 19
+    for blend in blends:
+        assert be.export_scene_json(str(blend)) == (SCENES / (blend.stem + ".json")).read_text(), blend.name
+
+
+def test_fixture_of_the_shipped_pair_is_the_scene_fixture():
+    assert (SCENES / "dof.json").read_text() == (cases.GOLDEN / "scene.json").read_text()
+
+
+@pytest.mark.parametrize("name,counts", [("bvh_vs_unaccel_5", (1, 6, 6, 6)), ("Test2", (2, 0, 140, 0)), ("Test1", (2, 20, 0, 1)),
+                                         ("texture_mapping1", (1, 1, 1, 1)), ("cube_mb", (1, 1, 1, 1))])
+def test_exported_scenes_load_through_the_host_surface(name, counts, textures_dir):
+    """The exported text goes through the same scanner as the reference's parser would use (rt_host_parse_scene)."""
+    text = (SCENES / f"{name}.json").read_text()
+    data = json.loads(text)["properties"]
+    cfg, _ = api.parse_args(["-t", "-m"])
+    ls = api.LoadedScene(text, cfg, textures_dir)
+    sc = ls.scene
+    assert (sc.n_lights, sc.n_spheres, sc.n_cubes, sc.n_planes) == counts
+    assert counts == (len(data["point_lights"]), len(data["spheres"]), len(data["cubes"]), len(data["planes"]))
+    if name == "texture_mapping1":
+        assert sc.n_textures == 1 and [m["material"]["texture"] for m in data["cubes"]] == ["tex2.ppm"]
+    if name == "cube_mb":
+        c = data["cubes"][0]
+        assert c["start_location"]["z"] == 0.0 and c["end_location"]["z"] == 5.0      # keyed at frames 1 and 10, sampled at 1 and 250
+    ls.close()
+
+
+def test_fcurve_evaluation():
+    lin = [((0, 0), (1.0, 2.0), (0, 0), 1), ((0, 0), (11.0, 4.0), (0, 0), 1)]
+    assert be._fcurve_value(lin, 0, 1.0) == 2.0 and be._fcurve_value(lin, 0, 11.0) == 4.0
+    assert be._fcurve_value(lin, 0, 6.0) == 3.0
+    assert be._fcurve_value(lin, 0, -5.0) == 2.0 and be._fcurve_value(lin, 0, 250.0) == 4.0     # constant extrapolation
+    const = [((0, 0), (1.0, 2.0), (0, 0), 0), ((0, 0), (11.0, 4.0), (0, 0), 0)]
+    assert be._fcurve_value(const, 0, 10.9) == 2.0
+    # a symmetric Bezier ease between (0,0) and (10,1) passes through (5, 0.5)
+    bez = [((-3.0, 0.0), (0.0, 0.0), (3.0, 0.0), 2), ((7.0, 1.0), (10.0, 1.0), (13.0, 1.0), 2)]
+    assert abs(be._fcurve_value(bez, 0, 5.0) - 0.5) < 1e-9
+    assert 0.0 < be._fcurve_value(bez, 0, 2.0) < 0.5 < be._fcurve_value(bez, 0, 8.0) < 1.0
+    with pytest.raises(NotImplementedError):
+        be._fcurve_value(lin, 1, 20.0)
+
+
+def test_rotation_matrix_and_vector_products():
+    m = be._object_matrix((1.0, 2.0, 3.0), (np.float32(math.pi / 2), 0.0, 0.0), (1.0, 1.0, 1.0))
+    fwd = be._normalized(be._mat_mul_vec(m, (0.0, 0.0, -1.0), 3))
+    # a camera pitched by float(pi/2) looks along +y; the z component is cos of the float angle, as in the shipped scene.json
+    assert float(fwd[0]) == 0.0 and float(fwd[1]) == 1.0 and float(fwd[2]) == 4.371138828673793e-08
+    p = be._mat_mul_vec(be._object_matrix((0.5, 0.0, -1.0), (0.0, 0.0, 0.0), (5.0, 5.0, 5.0)), (-1.0, 1.0, 0.0), 4)
+    assert [float(x) for x in p] == [-4.5, 5.0, -1.0]
