@@ -36,6 +36,11 @@ WORKLOADS = {
     # large-scene configuration, synthetic part: 1M random spheres/cubes over a ground plane (seed 42), BVH on
     "config3": dict(scene="random", n=1_000_000, res=(1920, 1080), flags=[]),
     "config3u": dict(scene="random", n=1_000_000, res=(1920, 1080), flags=["-u"]),
+    # large-scene configuration, the reference's own part: its 18-object Blender scene bvh_vs_unaccel_5, BVH on / off
+    "bvh5": dict(scene="blend:bvh_vs_unaccel_5", res=(1920, 1080), flags=[]),
+    "bvh5u": dict(scene="blend:bvh_vs_unaccel_5", res=(1920, 1080), flags=["-u"]),
+    # the reference's motion-blur scene with the multi-sample flag set at 1080p (64 samples per pixel)
+    "cube_mb": dict(scene="blend:cube_mb", res=(1920, 1080), flags=["-aa", "-aas", "4", "-dof", "-dofs", "4", "-m", "-mbs", "4", "-r", "-gr", "-grs", "4"]),
     "config4": dict(scene="ref", res=(3840, 2160), flags=["-aa", "-aas", "16", "-gr", "-grs", "16", "-dof", "-dofs", "16", "-m", "-mbs", "16"]),
 }
 HBM_PEAK_GBS = 8000.0
@@ -121,13 +126,20 @@ def cpu_baseline(workload: dict) -> dict:
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle
     import ref_runner
-    w, h = 800, 450
-    text = cases.reference_scene(w, h)
     flags = workload["flags"]
+    if workload["scene"] == "random":
+        return {"unit": "rays/s", "value": None, "cores": 1, "kind": "port",
+                "sample": "not run: the reference needs minutes per thousand pixels on this scene (every leaf of its depth-8 tree "
+                          "holds thousands of primitives); its rate on its own scenes is in the default workload's line"}
+    cfg, _ = api.parse_args(flags)
+    spp = max(1, cfg.samples_per_pixel())
+    scale = max(1, int(round(spp ** 0.5)))                       # keep the sample near 360 000 primary samples
+    w, h = max(32, 800 // scale), max(18, 450 // scale)
+    text = cases.reference_scene(w, h) if workload["scene"] == "ref" else cases.blend_scene(workload["scene"][6:], w, h)
     _, ost = oracle.render(text, flags, str(cases.TEXTURES))          # counts the rays the reference's code path traces
     rays = ost.total_rays()
     out = {"unit": "rays/s", "cores": 1,
-           "sample": f"scene.json at {w}x{h} ({w*h} of 2073600 pixels, same camera and flags), flags {' '.join(flags)}, {rays} rays "
+           "sample": f"{'scene.json' if workload['scene'] == 'ref' else workload['scene'][6:]} at {w}x{h} ({w*h} of {workload['res'][0] * workload['res'][1]} pixels, same camera and flags), flags {' '.join(flags)}, {rays} rays "
                      f"(the reference re-traces its 16 identical reflection rays per hit; all are counted)"}
     if ref_runner.have_ref():
         tex = {p.name: p for p in cases.TEXTURES.glob("*.ppm")}
@@ -179,6 +191,8 @@ def main():
     if rank == 0:
         if wl["scene"] == "ref":
             ls = api.LoadedScene(cases.reference_scene(W, H), cfg, str(cases.TEXTURES))
+        elif wl["scene"].startswith("blend:"):
+            ls = api.LoadedScene(cases.blend_scene(wl["scene"][6:], W, H), cfg, str(cases.TEXTURES))
         else:
             from raytracer_amd import scenegen as sg
             ls = api.ArrayScene(sg.random_prims(wl["n"], 42), (W, H))
@@ -268,14 +282,15 @@ def main():
             "value": rays_total / (elapsed / args.steps), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic: the reference's own ASCII/scene.json (committed as a fixture), no dataset" if wl["scene"] == "ref"
+                    else f"the reference's Blend/{wl['scene'][6:]}.blend exported to scene.json text (committed as a fixture)" if wl["scene"].startswith("blend:")
                     else f"synthetic: {wl['n']} random spheres/cubes (seed 42) over a ground plane, generated in-process",
-            "config": {"workload": f"{args.workload}: {'scene.json' if wl['scene'] == 'ref' else str(wl['n']) + ' random primitives'} {W}x{H}, flags {' '.join(wl['flags']) or '(none)'}",
+            "config": {"workload": f"{args.workload}: {'scene.json' if wl['scene'] == 'ref' else wl['scene'][6:] if wl['scene'].startswith('blend:') else str(wl['n']) + ' random primitives'} {W}x{H}, flags {' '.join(wl['flags']) or '(none)'}",
                        "spp": cfg.samples_per_pixel(), "tiles": "32x32 interleaved, rank = (tx+ty) % N",
                        "frame_ms_device_events": dev_ms / args.steps,
                        "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3],
                                           "hits_shaded": tot[5], "as_the_reference_would_trace_them": tot[0] + tot[4]},
                        "lit_fraction": lit},
-            "roofline": roofline(st, args.workload, wl["scene"] == "ref"),
+            "roofline": roofline(st, args.workload, wl["scene"] != "random"),
         }
         ceiling = copy_ceiling_GBps(dev)
         line["roofline"]["measured_copy_GBps"] = ceiling
