@@ -43,6 +43,9 @@ SCENES = {
     "blinn": lambda: blend_scene("blinn_phong_test", 200, 112),
     "test1": lambda: blend_scene("Test1", 200, 112),
     "test2": lambda: blend_scene("Test2", 160, 90),
+    **{name: (lambda n=name: blend_scene(n, 160, 90)) for name in
+       ("bvh_vs_unaccel_1", "bvh_vs_unaccel_2", "bvh_vs_unaccel_3", "bvh_vs_unaccel_4", "cube", "exported", "exported_rays", "scene",
+        "Test3", "test_personal_1", "test_personal_2", "texture_mapping2")},
     "ref120": lambda: reference_scene(120, 68),
     "glass": lambda: sg.glass_scene((200, 112)),
     "glass_tex": lambda: sg.glass_scene((200, 112), True),
@@ -88,6 +91,10 @@ DETERMINISTIC = [
     ("test1", ["-rd", "2", "-grs", "1"]),
     ("test2", []),
     ("test2", ["-u"]),
+    # every other Blender scene of the reference (scene.blend has no light, exported*.blend two moving objects)
+    *[(name, flags) for name in ("bvh_vs_unaccel_1", "bvh_vs_unaccel_2", "bvh_vs_unaccel_3", "bvh_vs_unaccel_4", "cube", "exported",
+                                 "exported_rays", "scene", "Test3", "test_personal_1", "test_personal_2", "texture_mapping2")
+      for flags in ([], ["-u", "-rd", "2", "-grs", "1", "-t"])],
 ]
 
 # Stochastic flag sets: judged by PSNR >= 40 dB between two high-sample renders (the golden one is the reference's).
