@@ -47,11 +47,17 @@ def random_flags(rng):
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--cases", type=int, default=60); ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--blender-scenes", action="store_true", help="random flag sets and film sizes on the reference's own Blender scenes")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     bad = 0; worst = 0
+    names = sorted(p.stem for p in (cases.GOLDEN / "scenes").glob("*.json"))
     for k in range(args.cases):
-        text = random_scene(rng, (96, 54)); flags = random_flags(rng)
+        if args.blender_scenes:
+            w = int(rng.integers(40, 140)); h = int(rng.integers(30, 90))
+            text = cases.blend_scene(names[k % len(names)], w, h); flags = random_flags(rng)
+        else:
+            text = random_scene(rng, (96, 54)); flags = random_flags(rng)
         ref, ost = oracle.render(text, flags, str(cases.TEXTURES))
         img, st = api.render_scene_text(text, flags, str(cases.TEXTURES))
         d = np.abs(img.astype(np.int32) - ref)
