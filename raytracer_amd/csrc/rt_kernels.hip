@@ -11,6 +11,8 @@
 #include <math.h>
 
 #define DEVI __device__ __forceinline__
+#define RL_FN __device__ __forceinline__
+#include "ref_libm.h"
 
 // minimum wavefronts per SIMD the register allocator must leave room for (second __launch_bounds__ argument)
 #ifndef RT_EXTEND_WAVES
@@ -123,8 +125,9 @@ DEVI bool sphere_test(const float4* __restrict__ rec, const Ray& r, bool mb, boo
         h->gid = f2i(w1.w);
         if (want_uv) {                                                   // sphere.cpp:152-162
             V3 nn = normalise(ip - loc);
-            h->u = (float)((double)0.5f + (double)atan2f(nn.z, nn.x) / (2 * M_PI));
-            h->v = (float)((double)0.5f - (double)asinf(nn.y) / M_PI);
+            // atan2 / asin on floats are the C library's single-precision routines, reproduced bit for bit (ref_libm.h)
+            h->u = (float)((double)0.5f + (double)rl_atan2f(nn.z, nn.x) / (2 * M_PI));
+            h->v = (float)((double)0.5f - (double)rl_asinf(nn.y, [](float t) { return sqrtf(t); }) / M_PI);
         }
     }
     return true;
