@@ -63,6 +63,8 @@ def main():
         d = np.abs(img.astype(np.int32) - ref)
         npx = int((d.max(axis=2) > 0).sum()); worst = max(worst, int(d.max()))
         rays_ok = (st.primary_rays, st.shadow_rays_ref, st.reflection_rays_ref, st.refraction_rays_ref) == (ost.primary, ost.shadow, ost.reflection, ost.refraction)
+        if k % 200 == 199:
+            print(f"... {k + 1} cases", flush=True)
         if npx or not rays_ok:
             bad += 1
             print(f"case {k} seed {args.seed} flags {flags}: {npx} pixels differ, max {int(d.max())} LSB, rays equal: {rays_ok}", flush=True)
