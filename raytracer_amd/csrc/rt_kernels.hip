@@ -19,7 +19,7 @@
 #define RT_EXTEND_WAVES 4           // scenes without second-level hierarchies: a few spills, better co-residency
 #endif
 #ifndef RT_EXTEND_WAVES_SUB
-#define RT_EXTEND_WAVES_SUB 3       // the hierarchy walk needs the registers
+#define RT_EXTEND_WAVES_SUB 4       // the hierarchy walk is latency-bound: a fourth wavefront beats the spills it costs
 #endif
 #ifndef RT_SHADOW_WAVES
 #define RT_SHADOW_WAVES 4
