@@ -194,6 +194,7 @@ struct rt_ctx {
     int device_build = 1;                    // hierarchies and leaf-order records are made on the GPU (rt_set_option)
     bool built_on_device = false;            // what the current scene's upload used
     long long n_file_nodes = 0, n_file_entries = 0;
+    int file_sub_depth = 0;                  // depth of the file-order hierarchy
     double sphere_e = 0.0;                   // rounding allowance of the float sphere test, see rt_upload_scene
     DevBuf<float4> d_sub_nodes_file, d_sub_nodes;   // file-order set alone / file-order set followed by the leaves'
     DevBuf<int> d_sub_entries_file, d_sub_entries, d_prim_ids;
@@ -504,7 +505,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
         return 6e-7 * diag2;
     };
     Box3 all; all.clear();
-    c->sphere_e = 0.0; c->file_sub_root = -1; c->n_file_nodes = 0; c->n_file_entries = 0;
+    c->sphere_e = 0.0; c->file_sub_root = -1; c->n_file_nodes = 0; c->n_file_entries = 0; c->file_sub_depth = 0;
     c->h_sub_nodes_file.clear(); c->h_sub_entries_file.clear();
     c->tb_planes.clear(); c->tb_cubes.clear(); c->tb_spheres.clear();
     if (on_device) {
@@ -514,7 +515,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
         if (ns > 0) c->sphere_e = sphere_allowance(raw);
         BuildGroup g{}; g.pn = np; g.cn = nc; g.sn = ns; g.n = np + nc + ns; g.depth = rt_build_depth(g.n);
         if (g.depth + 2 > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_STACK - 2);
-        c->n_file_nodes = (1ll << g.depth) - 1; c->n_file_entries = g.n;
+        c->n_file_nodes = (1ll << g.depth) - 1; c->n_file_entries = g.n; c->file_sub_depth = g.depth;
         RT_HIP(c, c->d_sub_nodes_file.resize((size_t)c->n_file_nodes * 4));
         RT_HIP(c, c->d_sub_entries_file.resize((size_t)c->n_file_entries));
         float fin[6];
@@ -551,7 +552,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
             SubBuilder sb{ c->h_sub_nodes_file, c->h_sub_entries_file };
             SubRef root = sb.build(items, 0, items.size(), 0);
             if (sb.max_depth + 2 > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_STACK - 2);
-            c->file_sub_root = root.ref;
+            c->file_sub_root = root.ref; c->file_sub_depth = sb.max_depth;
         }
         c->n_file_nodes = (long long)(c->h_sub_nodes_file.size() / 4); c->n_file_entries = (long long)c->h_sub_entries_file.size();
         RT_HIP(c, c->d_sub_nodes_file.upload(c->h_sub_nodes_file, s));
@@ -570,6 +571,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
     d.lights = c->d_lights.p; d.n_lights = sc->n_lights;
     d.sub_nodes = c->n_file_nodes ? c->d_sub_nodes_file.p : nullptr;
     d.sub_entries = c->d_sub_entries_file.p; d.file_sub_root = c->file_sub_root;
+    d.sub_stack_entries = std::max(4, c->file_sub_depth + 2);
     d.n_verts = sc->n_plane_verts;
     d.lds_prims = (!d.sub_nodes && rt_lds_prim_words(d) <= RT_LDS_PRIM_MAX_WORDS) ? c->lds_prims : 0;
     for (int k = 0; k < 3; ++k) d.center[k] = centre[k];
@@ -591,6 +593,8 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
     DevScene& d = c->scene;
     d.n_nodes = 0; d.n_leaves = 0;
     d.sub_nodes = c->n_file_nodes ? c->d_sub_nodes_file.p : nullptr; d.sub_entries = c->d_sub_entries_file.p;
+    d.sub_stack_entries = std::max(4, c->file_sub_depth + 2);
+    int deepest = c->file_sub_depth;
     if (!nodes || n_nodes <= 0) return RT_OK;
     if (n_prim_ids < 0 || (n_prim_ids && !prim_ids)) return c->fail(RT_ERR_ARG, "bad prim_ids");
     const int np = c->np, nc = c->nc, ns = c->ns;
@@ -694,7 +698,7 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
             BuildGroup b{}; b.p0 = L.lp0; b.pn = L.n_planes; b.c0 = L.lc0; b.cn = L.n_cubes; b.s0 = L.ls0; b.sn = L.n_spheres;
             b.n = (int)cnt; b.depth = rt_build_depth(cnt); b.item_base = (int)n_items; b.node_base = (int)total_nodes;
             if (b.depth + 2 > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_STACK - 2);
-            leaves[2 * g + 1].z = b.node_base;
+            leaves[2 * g + 1].z = b.node_base; deepest = std::max(deepest, b.depth);
             n_items += cnt; total_nodes += (1ll << b.depth) - 1;
             groups.push_back(b);
         }
@@ -732,7 +736,7 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
                 SubBuilder sb{ sub_nodes, sub_entries };
                 SubRef root = sb.build(items, 0, items.size(), 0);
                 if (sb.max_depth + 2 > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_STACK - 2);
-                leaves[2 * g + 1].z = root.ref;
+                leaves[2 * g + 1].z = root.ref; deepest = std::max(deepest, sb.max_depth);
             }
         }
         total_nodes = (long long)(sub_nodes.size() / 4); total_entries = (long long)sub_entries.size();
@@ -751,6 +755,7 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
     d.nodes = c->d_nodes.p; d.n_nodes = (int)out.size();
     d.leaves = c->d_leaves.p; d.n_leaves = (int)(leaves.size() / 2);
     d.leafset = leafset;
+    d.sub_stack_entries = std::max(4, deepest + 2);
     d.lds_prims = (!d.sub_nodes && rt_lds_prim_words(d) <= RT_LDS_PRIM_MAX_WORDS) ? c->lds_prims : 0;
     c->have_bvh = true;
     return RT_OK;

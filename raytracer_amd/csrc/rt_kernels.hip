@@ -514,9 +514,9 @@ DEVI void full_hit(const DevScene& sc, const DevFrame& f, const Ray& r, const Be
 }
 
 // Copy the BVH nodes and leaf records into LDS with coalesced 16-byte loads (one pass per workgroup).
-DEVI void stage_bvh(const DevScene& sc, float4* s_nodes, int4* s_leaves) {
+DEVI void stage_bvh(const DevScene& sc, float4* s_nodes, int4* s_leaves, bool with_leaves) {
     for (int i = threadIdx.x; i < 2 * sc.n_nodes; i += blockDim.x) s_nodes[i] = sc.nodes[i];
-    for (int i = threadIdx.x; i < 2 * sc.n_leaves; i += blockDim.x) s_leaves[i] = sc.leaves[i];
+    if (with_leaves) for (int i = threadIdx.x; i < 2 * sc.n_leaves; i += blockDim.x) s_leaves[i] = sc.leaves[i];
     __syncthreads();
 }
 
@@ -625,12 +625,14 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
     extern __shared__ float4 s_mem[];
     DevScene sc = sc_arg;
     float4* s_nodes = s_mem;
-    int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
-    int* s_stack = (int*)(s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves) + threadIdx.x;   // [depth][thread]
+    // with second-level hierarchies the LDS budget goes to the traversal stacks (occupancy): leaf records, read once
+    // per leaf visit, then stay in global memory
+    const int4* s_leaves = SUB ? sc.leaves : (const int4*)(s_mem + 2 * sc.n_nodes);
+    int* s_stack = (int*)(s_mem + 2 * sc.n_nodes) + threadIdx.x;                      // [depth][thread], only with SUB
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
     const int count = PRIMARY ? f.pix_count : min(w.ctr[RT_CTR_LINK(level)], w.link_off[level + 1] - w.link_off[level]);
     if ((int)(blockIdx.x * blockDim.x) >= count) return;               // whole workgroup idle
-    if (f.use_bvh) stage_bvh(sc, s_nodes, s_leaves);
+    if (f.use_bvh) stage_bvh(sc, s_nodes, (int4*)(s_mem + 2 * sc.n_nodes), !SUB);
     if (LDSP) stage_prims(sc, s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves);
 
     const int link_in = PRIMARY ? 0 : w.link_off[level];
@@ -793,8 +795,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene s
     extern __shared__ float4 s_mem[];
     DevScene sc = sc_arg;
     float4* s_nodes = s_mem;
-    int4* s_leaves = (int4*)(s_mem + 2 * sc.n_nodes);
-    int* s_stack = (int*)(s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves) + threadIdx.x;   // [depth][thread]
+    // with second-level hierarchies the LDS budget goes to the traversal stacks (occupancy): leaf records, read once
+    // per leaf visit, then stay in global memory
+    const int4* s_leaves = SUB ? sc.leaves : (const int4*)(s_mem + 2 * sc.n_nodes);
+    int* s_stack = (int*)(s_mem + 2 * sc.n_nodes) + threadIdx.x;                      // [depth][thread], only with SUB
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
     __shared__ int s_first[RT_MAX_LEVELS];                              // dense index of each level's first hit
     if (threadIdx.x == 0) {
@@ -813,7 +817,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene s
     const unsigned per = (unsigned)(L * SS);
     const unsigned count = (unsigned)n_nodes * per;                      // the host keeps hits x lights x samples below 2^31
     if (blockIdx.x * blockDim.x >= count) return;
-    if (f.use_bvh) stage_bvh(sc, s_nodes, s_leaves);
+    if (f.use_bvh) stage_bvh(sc, s_nodes, (int4*)(s_mem + 2 * sc.n_nodes), !SUB);
     if (LDSP) stage_prims(sc, s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves);
 
     const unsigned stride = gridDim.x * blockDim.x;
@@ -1043,8 +1047,9 @@ __global__ void k_begin_frame(float4* __restrict__ accum, int n_slots, int* __re
 // second-level hierarchy, one traversal stack per thread.  The kernels index from n_nodes / n_leaves, which the
 // context zeroes when no BVH is uploaded.
 static size_t bvh_lds_bytes(const DevScene& sc, const DevFrame& f) {
-    size_t b = (size_t)(2 * sc.n_nodes + 2 * sc.n_leaves) * 16;
-    if (sc.sub_nodes) b += (size_t)RT_BLOCK * RT_SUB_STACK * sizeof(int);
+    size_t b = (size_t)(2 * sc.n_nodes) * 16;
+    if (sc.sub_nodes) b += (size_t)RT_BLOCK * (size_t)sc.sub_stack_entries * sizeof(int);
+    else b += (size_t)(2 * sc.n_leaves) * 16;
     if (sc.lds_prims) b += (size_t)rt_lds_prim_words(sc) * 16;
     return b ? b : 16;
 }

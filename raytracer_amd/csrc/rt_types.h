@@ -14,7 +14,7 @@
 #define RT_MAX_LDS_LEAVES  512       // leaf records staged in LDS (32 B each)
 #define RT_SUB_LEAF        4         // second-level hierarchy: primitives per entry run
 #define RT_SUB_MIN_GROUP   8         // groups of at most this many primitives are tested one by one
-#define RT_SUB_STACK       26        // second-level traversal stack entries per thread (LDS)
+#define RT_SUB_STACK       26        // most second-level traversal stack entries per thread (LDS); a scene uses depth + 2
 
 // ---- primitives ---------------------------------------------------------------------------------------
 // A primitive set is one ordering of the scene's primitives: leaf order (BVH traversal) or file order
@@ -60,6 +60,7 @@ struct DevScene {
     const float4* sub_nodes;       // second-level hierarchies of all groups (NULL when no group has one)
     const int* sub_entries;
     int file_sub_root;             // second-level root over the whole file-order set, or -1
+    int sub_stack_entries;         // traversal stack entries per thread = deepest hierarchy + 2
     int n_verts;                   // polygon vertices of all planes
     int lds_prims;                 // tiny scene: kernels keep the primitive records and materials in LDS
     float center[3], radius;       // sphere around the true bounds of everything in the scene
