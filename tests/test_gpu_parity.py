@@ -399,3 +399,33 @@ def test_pipelined_frames_two_shards_in_one_process():
     for r in rs + [single]:
         r.close()
     ls.close()
+
+
+@pytest.mark.parametrize("kind", ["coincident", "collinear", "nonfinite", "nine", "huge"])
+def test_degenerate_populations_build_and_render_like_the_plain_search(kind):
+    """Hierarchy construction on populations that break assumptions of a spatial sort: every centre identical, all on
+    a line, non-finite coordinates, a group just above the threshold, coordinates spanning 10^12.  The frame must equal
+    the one rendered with the primitives searched one by one, with device-built and host-built hierarchies."""
+    rng = np.random.default_rng(3)
+    n = 9 if kind == "nine" else 600
+    t = sg.random_prims(n, 9)
+    if kind == "coincident":
+        t[:, 0:3] = (0.5, 4.0, 1.5); t[:, 3] = np.linspace(0.2, 0.9, n)
+    elif kind == "collinear":
+        t[:, 0] = np.linspace(-6, 6, n); t[:, 1] = 5.0; t[:, 2] = 1.0
+    elif kind == "nonfinite":
+        t[::7, 0] = np.nan; t[3::11, 1] = np.inf; t[5::13, 3] = np.nan
+    elif kind == "huge":
+        t[::5, 0] *= 1e12; t[1::5, 2] = -1e12; t[2::5, 3] = 1e6
+    cfg, _ = api.parse_args(["-rd", "1", "-grs", "1"])
+    got = []
+    for opts in ({"second_level_min_group": 1 << 40}, {"device_build": 1}, {"device_build": 0}):
+        ls = api.ArrayScene(t, (160, 90))
+        r = api.Renderer(0)
+        for k, v in opts.items():
+            r.set_option(k, v)
+        r.upload(ls)
+        img, st = r.render(cfg)
+        got.append((img, st.shadow_rays_ref, st.reflection_rays_ref)); r.close(); ls.close()
+    for img, a, b in got[1:]:
+        assert np.array_equal(img, got[0][0]) and (a, b) == got[0][1:], kind
