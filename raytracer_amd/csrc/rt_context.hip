@@ -935,8 +935,9 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
                 }
             }
             if (L > 0) { tm->begin(ST_SHADOW); rt_launch_shadow(s, c->scene, f, w, split ? 1 : 0, D, max_grid); tm->end(); }
-            if (overlap) RT_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
             for (int level = D; level >= 0; --level) {
+                // only the primary hits' shading needs the forked launch; the deeper levels resolve beside it
+                if (overlap && level == 0) RT_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
                 tm->begin(ST_SHADE);
                 rt_launch_shade(s, c->scene, f, w, level, level == 0 ? grid0 : max_grid);
                 tm->end();
