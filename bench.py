@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="contexts rendering consecutive frames concurrently on their own streams (1 = one frame at a time)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a one-GPU machine: every rank uses GPU 0 (use with --backend gloo)")
@@ -202,15 +204,28 @@ def main():
         r.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     r.upload(ls, with_bvh=bool(cfg.bvh))
     r.set_shard(rank, world)
-    # Everything of a step runs on one explicit side stream: the render kernels, the RCCL gather (torch orders its
-    # communication stream against the current stream) and the timing events.
-    stream = torch.cuda.Stream(dev)
+    # Everything of a step runs on the context's own stream, which torch sees as an external stream (the RCCL gather
+    # is ordered against it).  No further streams are created for rendering: a process has few hardware queues, and
+    # two render streams that share one do not overlap.
+    stream = torch.cuda.ExternalStream(r.stream_handle(), device=dev)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
-    r.set_stream(stream.cuda_stream)
 
     block = torch.empty(r.out_bytes(), dtype=torch.uint8, device=dev)
     image = torch.empty(H * W * 3, dtype=torch.uint8, device=dev) if rank == 0 else None
+
+    # Frames in flight: consecutive frames are independent, so P contexts (each with its own work buffers and streams)
+    # render them concurrently; a frame's small launches (deep recursion levels) then fill the other frame's gaps.
+    # Not used for frames of many batches, which keep the GPU busy on their own.
+    P = max(1, args.frames_in_flight) if cfg.samples_per_pixel() <= 64 else 1
+    ctxs = [(r, stream, block)]
+    for _ in range(P - 1):
+        r2 = api.Renderer(local, workspace_bytes=16 << 30)
+        for kv in filter(None, os.environ.get("RT_BENCH_OPTS", "").split(",")):
+            r2.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+        r2.upload(ls, with_bvh=bool(cfg.bvh)); r2.set_shard(rank, world)
+        s2 = torch.cuda.ExternalStream(r2.stream_handle(), device=dev)
+        ctxs.append((r2, s2, torch.empty_like(block)))
 
     staged = args.backend == "gloo"      # rehearsal path: gloo moves host tensors
 
@@ -219,11 +234,17 @@ def main():
     # frame k + 1.  Buffers are reused every other frame behind events; the timed region ends with a device-wide
     # synchronisation, so every frame's image has reached rank 0 inside it.
     pipelined = world > 1 and not staged
-    pipe = rdist.FramePipeline(r, cfg, rank, world, dev, stream) if pipelined else None
+    pipes = [rdist.FramePipeline(rr, cfg, rank, world, dev, ss) for rr, ss, _ in ctxs] if pipelined else None
+    frame_no = [0]
 
     def step():
+        k = frame_no[0] % P; frame_no[0] += 1
         if pipelined:
-            pipe.step()
+            pipes[k].step()
+            return None
+        if world == 1:
+            rr, _, bb = ctxs[k]
+            rr.render_device(cfg, bb.data_ptr())
             return None
         r.render_device(cfg, block.data_ptr())
         if world > 1:
@@ -251,22 +272,26 @@ def main():
     tot = [int(x) for x in rays_local.tolist()]
     rays_total = tot[0] + tot[1] + tot[2] + tot[3]
 
-    for _ in range(args.warmup):
+    # latency of one frame alone (enqueue -> done), next to the throughput the timed loop measures
+    torch.cuda.synchronize(dev)
+    t_lat = time.perf_counter()
+    for _ in range(10):
+        r.render_device(cfg, block.data_ptr()); r.synchronize()
+    frame_latency_ms = (time.perf_counter() - t_lat) * 100.0
+    warm_steps = max(args.warmup, 2 * P)             # every context records its frame graph on its second frame
+    for _ in range(warm_steps):
         step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(stream)
     for _ in range(args.steps):
         step()
-    ev1.record(stream)
+    t_enq = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staged else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -275,18 +300,21 @@ def main():
     if rank == 0:
         ms_per_step = 1000.0 * elapsed / args.steps
         # rank-0 sanity: the frame is not black and (N=1) is the row-major image itself
-        final = ((pipe.image if pipelined else image) if world > 1 else block).cpu().numpy()
+        last = (frame_no[0] - 1) % P
+        final = ((pipes[last].image if pipelined else image) if world > 1 else ctxs[last][2]).cpu().numpy()
         lit = float((final.reshape(-1, 3).sum(axis=1) > 0).mean())
         line = {
             "metric": "rays/sec (all ray types), 1080p scene.json" if args.workload == "config2" else f"rays/sec (all ray types), {args.workload}",
-            "value": rays_total / (elapsed / args.steps), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": rays_total / (elapsed / args.steps), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": warm_steps,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic: the reference's own ASCII/scene.json (committed as a fixture), no dataset" if wl["scene"] == "ref"
                     else f"the reference's Blend/{wl['scene'][6:]}.blend exported to scene.json text (committed as a fixture)" if wl["scene"].startswith("blend:")
                     else f"synthetic: {wl['n']} random spheres/cubes (seed 42) over a ground plane, generated in-process",
             "config": {"workload": f"{args.workload}: {'scene.json' if wl['scene'] == 'ref' else wl['scene'][6:] if wl['scene'].startswith('blend:') else str(wl['n']) + ' random primitives'} {W}x{H}, flags {' '.join(wl['flags']) or '(none)'}",
                        "spp": cfg.samples_per_pixel(), "tiles": "32x32 interleaved, rank = (tx+ty) % N",
-                       "frame_ms_device_events": dev_ms / args.steps,
+                       "frames_in_flight": P, "frame_ms_alone": frame_latency_ms, "host_enqueue_ms_per_step": 1000.0 * t_enq / args.steps,
+                       "timing": "ms_per_step = timed wall clock / steps with frames_in_flight independent frames overlapping on the GPU; "
+                                 "frame_ms_alone = one frame enqueued and waited for by itself",
                        "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3],
                                           "hits_shaded": tot[5], "as_the_reference_would_trace_them": tot[0] + tot[4]},
                        "lit_fraction": lit},
@@ -301,7 +329,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    r.close(); ls.close()
+    for rr, _, _ in ctxs:
+        rr.close()
+    ls.close()
 
 
 if __name__ == "__main__":

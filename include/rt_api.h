@@ -179,6 +179,10 @@ void rt_destroy(rt_ctx* ctx);
 
 /* Work is enqueued on `hip_stream` (a hipStream_t; NULL = the context's own stream). */
 int rt_set_stream(rt_ctx* ctx, void* hip_stream);
+/* The hipStream_t work is currently enqueued on (the context's own stream unless rt_set_stream replaced it), so that
+ * a caller can order its own work against it without creating another stream: every extra stream of a process may
+ * end up sharing one of the few hardware queues with a render stream. */
+void* rt_get_stream(rt_ctx* ctx);
 
 /* Implementation options (no counterpart in the reference; none of them changes a rendered value). Set before
  * rt_upload_scene.  "second_level_min_group" = N: groups of more than N primitives (a leaf of the reference's

@@ -110,7 +110,7 @@ class HostBvh(C.Structure):
 
 
 # every symbol the two headers declare
-API_SYMBOLS = ["rt_default_config", "rt_create", "rt_destroy", "rt_set_stream", "rt_set_option", "rt_upload_scene", "rt_upload_bvh",
+API_SYMBOLS = ["rt_default_config", "rt_create", "rt_destroy", "rt_set_stream", "rt_get_stream", "rt_set_option", "rt_upload_scene", "rt_upload_bvh",
                "rt_set_shard", "rt_local_tiles", "rt_max_tiles_per_rank", "rt_render", "rt_render_device",
                "rt_assemble_tiles", "rt_synchronize", "rt_last_error"]
 HOST_SYMBOLS = ["rt_host_parse_args", "rt_host_parse_scene", "rt_host_load_scene", "rt_host_free_scene",
@@ -132,6 +132,7 @@ def lib():
     L.rt_create.argtypes = [C.c_int, C.c_uint64]; L.rt_create.restype = C.c_void_p
     L.rt_destroy.argtypes = [C.c_void_p]; L.rt_destroy.restype = None
     L.rt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.rt_get_stream.argtypes = [C.c_void_p]; L.rt_get_stream.restype = C.c_void_p
     L.rt_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.rt_upload_scene.argtypes = [C.c_void_p, C.POINTER(Scene)]
     L.rt_upload_bvh.argtypes = [C.c_void_p, C.POINTER(BvhNode), C.c_int32, C.POINTER(C.c_int32), C.c_int32]
@@ -431,6 +432,10 @@ class Renderer:
 
     def set_stream(self, stream_handle: int | None):
         self._check(lib().rt_set_stream(self._ctx, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def stream_handle(self) -> int:
+        """The hipStream_t the context enqueues on (wrap it with torch.cuda.ExternalStream to order torch work against it)."""
+        return int(lib().rt_get_stream(self._ctx) or 0)
 
     def set_option(self, name: str, value: int):
         self._check(lib().rt_set_option(self._ctx, name.encode(), value))

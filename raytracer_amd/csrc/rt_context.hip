@@ -312,6 +312,8 @@ int rt_set_stream(rt_ctx* c, void* hip_stream) {
     return RT_OK;
 }
 
+void* rt_get_stream(rt_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
 int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return RT_ERR_ARG;
     if (std::strcmp(name, "second_level_min_group") == 0) {

@@ -98,7 +98,8 @@ class FramePipeline:
     """Frames of a multi-rank run, pipelined: frame k is rendered on `render_stream` into one of two blocks; its gather
     runs beside the kernels of frame k + 1 (on the communicator's stream) and rank 0 re-orders it into the row-major
     image on a third stream.  Buffers are reused every other frame behind the gather handle and an event.
-    `start_gather(block, out_or_None)` returns a handle whose wait() makes the current stream wait for the transfer
+    `render_stream` must be the stream the renderer enqueues on (torch.cuda.ExternalStream(renderer.stream_handle()), or
+    a torch stream handed to renderer.set_stream beforehand).  `start_gather(block, out_or_None)` returns a handle whose wait() makes the current stream wait for the transfer
     (gather_blocks_async over RCCL; tests substitute device copies)."""
 
     def __init__(self, renderer, cfg, rank: int, world: int, device, render_stream, start_gather=gather_blocks_async):
@@ -122,8 +123,7 @@ class FramePipeline:
                 self.pending[b].wait()                          # the gather that last read blocks[b], two frames ago
             if self.asm_done[b] is not None:
                 self.stream.wait_event(self.asm_done[b])        # the re-ordering that last read gathered[b]
-            self.r.set_stream(self.stream.cuda_stream)
-            self.r.render_device(self.cfg, self.blocks[b].data_ptr())
+            self.r.render_device(self.cfg, self.blocks[b].data_ptr())             # on render_stream, the context's stream
             self.pending[b] = self.start_gather(self.blocks[b], self.gathered[b])
         if self.rank == 0:
             with torch.cuda.stream(self.asm_stream):

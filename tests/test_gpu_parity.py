@@ -381,7 +381,8 @@ def test_pipelined_frames_two_shards_in_one_process():
             return h
         return start
 
-    pipes = [rdist.FramePipeline(rs[k], copy.copy(cfg), k, world, dev, torch.cuda.Stream(dev), make_gather(k)) for k in range(world)]
+    pipes = [rdist.FramePipeline(rs[k], copy.copy(cfg), k, world, dev, torch.cuda.ExternalStream(rs[k].stream_handle(), device=dev), make_gather(k))
+             for k in range(world)]
     frames = 7
     for frame in range(frames):
         for k in (1, 0):
