@@ -905,7 +905,14 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     w.cap_nodes = (unsigned)cap_nodes;
     for (int d = 0; d <= D + 2 && d < RT_MAX_LEVELS; ++d) { w.node_off[d] = (int)node_off[(size_t)std::min(d, D + 1)]; w.link_off[d] = (int)link_off[(size_t)d]; }
 
-    rt_launch_begin_frame(s, w, (int)n_slots, want_stats_zero);      // per-pixel sums, first batch's counters, statistics
+    const int tile_major = c->world > 1;
+    const size_t out_bytes = tile_major ? (size_t)c->max_tiles * RT_TILE_PIX * 3 : (size_t)f.width * (size_t)f.height * 3;
+    // One sample per pixel in a single batch: the level-0 shading writes the pixels itself; the frame start then zeroes
+    // the image (pixels without a hit stay black) instead of the per-pixel sums, and there is no finalize pass.
+    const bool direct = S == 1 && B >= n_slots && ((uintptr_t)out_dev % 16) == 0;
+    f.direct_out = direct ? out_dev : nullptr; f.direct_tile_major = tile_major;
+    if (direct) rt_launch_begin_frame(s, w, out_dev, out_bytes, want_stats_zero);
+    else rt_launch_begin_frame(s, w, c->accum.p, (size_t)n_slots * sizeof(float4), want_stats_zero);
 
     const int max_grid = 2048;       // 256 CUs x 8 workgroups: enough to fill the chip, grid-stride beyond that
     unsigned long long batches = 0;
@@ -947,14 +954,15 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
             ++batches;
         }
     }
-    const int tile_major = c->world > 1;
-    if (tile_major) {
-        size_t total = (size_t)c->max_tiles * RT_TILE_PIX * 3, used = (size_t)n_slots * 3;
-        if (total > used) RT_HIP(c, hipMemsetAsync(out_dev + used, 0, total - used, s));
+    if (!direct) {
+        if (tile_major) {
+            size_t used = (size_t)n_slots * 3;
+            if (out_bytes > used) RT_HIP(c, hipMemsetAsync(out_dev + used, 0, out_bytes - used, s));
+        }
+        tm->begin(ST_OTHER);
+        rt_launch_finalize(s, f, w, out_dev, tile_major, (int)n_slots, S);
+        tm->end();
     }
-    tm->begin(ST_OTHER);
-    rt_launch_finalize(s, f, w, out_dev, tile_major, (int)n_slots, S);
-    tm->end();
     RT_HIP(c, hipGetLastError());
     c->err.clear();
     c->last_batches = batches;

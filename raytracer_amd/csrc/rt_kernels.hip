@@ -879,6 +879,23 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene s
     block_stat_add(&w.stats[RT_S_SHADOW], n_rays, s_tmp);
 }
 
+// raytracer.cpp:173-178: truncate a colour to 0..255 and store it at the pixel of a local slot (row-major image, or
+// this rank's tile-major block).  A wavefront's slots that reach here together lie in one tile only in k_finalize.
+DEVI void store_pixel(const DevFrame& f, unsigned char* __restrict__ out, int tile_major, int slot, float cr, float cg, float cb) {
+    int r = (int)(255.0f * cr), g = (int)(255.0f * cg), b = (int)(255.0f * cb);
+    if (tile_major) {
+        out[3 * slot] = (unsigned char)r; out[3 * slot + 1] = (unsigned char)g; out[3 * slot + 2] = (unsigned char)b;
+    } else {
+        int tile_local = slot / RT_TILE_PIX, in = slot % RT_TILE_PIX;
+        int gt = f.local_tiles[tile_local];
+        int x = (gt % f.tiles_x) * RT_TILE + (in % RT_TILE), y = (gt / f.tiles_x) * RT_TILE + (in / RT_TILE);
+        if (x < f.width && y < f.height) {
+            size_t o = ((size_t)y * f.width + x) * 3;
+            out[o] = (unsigned char)r; out[o + 1] = (unsigned char)g; out[o + 2] = (unsigned char)b;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // shade + resolve for one recursion level, deepest level first: Blinn-Phong at the hit (raytracer.cpp:262-347),
 // then the parent's combination of its children's colours with both clamps (raytracer.cpp:436-503).  Level 0
@@ -973,8 +990,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, Dev
         w.n_col[node] = make_float4(col.x, col.y, col.z, 0.0f);
         if (level == 0) {
             const int slot = w.n_pix[node];
-            float4 acc = w.accum[slot];
-            w.accum[slot] = make_float4(acc.x + col.x, acc.y + col.y, acc.z + col.z, 0.0f);
+            if (f.direct_out) {
+                // one sample per pixel in one batch: the sum is this colour and the average divides by one, so the
+                // pixel can be written now (the frame start zeroed the image instead of the sums)
+                store_pixel(f, f.direct_out, f.direct_tile_major, slot, col.x * 1.0f, col.y * 1.0f, col.z * 1.0f);
+            } else {
+                float4 acc = w.accum[slot];
+                w.accum[slot] = make_float4(acc.x + col.x, acc.y + col.y, acc.z + col.z, 0.0f);
+            }
         }
     }
     block_stat_add(&w.stats[RT_S_NODES], n_shaded, s_tmp);
@@ -985,20 +1008,7 @@ __global__ void k_finalize(DevFrame f, DevWork w, unsigned char* __restrict__ ou
     const float inv = 1.0f / (float)samples;
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_slots; slot += gridDim.x * blockDim.x) {
         float4 acc = w.accum[slot];
-        int r = (int)(255.0f * (acc.x * inv)), g = (int)(255.0f * (acc.y * inv)), b = (int)(255.0f * (acc.z * inv));
-        if (tile_major) {
-            out[3 * slot] = (unsigned char)r; out[3 * slot + 1] = (unsigned char)g; out[3 * slot + 2] = (unsigned char)b;
-        } else {
-            int tile_local = slot / RT_TILE_PIX, in = slot % RT_TILE_PIX;
-            // a wavefront's 64 slots lie in one tile (batches start at multiples of 64): one scalar load, which does not
-    // queue behind the vector stores of the previous round
-    int gt = f.local_tiles[__builtin_amdgcn_readfirstlane(tile_local)];
-            int x = (gt % f.tiles_x) * RT_TILE + (in % RT_TILE), y = (gt / f.tiles_x) * RT_TILE + (in / RT_TILE);
-            if (x < f.width && y < f.height) {
-                size_t o = ((size_t)y * f.width + x) * 3;
-                out[o] = (unsigned char)r; out[o + 1] = (unsigned char)g; out[o + 2] = (unsigned char)b;
-            }
-        }
+        store_pixel(f, out, tile_major, slot, acc.x * inv, acc.y * inv, acc.z * inv);
     }
 }
 
@@ -1029,12 +1039,14 @@ __global__ void k_assemble(const unsigned char* __restrict__ tiles, int world, i
 
 } // namespace
 
-// Start of a frame: zero the per-pixel sums, the first batch's counters and (optionally) the ray statistics in one
-// launch instead of three fills.
-__global__ void k_begin_frame(float4* __restrict__ accum, int n_slots, int* __restrict__ ctr, unsigned long long* __restrict__ stats) {
-    const int stride = gridDim.x * blockDim.x;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) accum[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+
+// Start of a frame: zero the per-pixel sums (or, for frames that write their pixels directly, the image), the first
+// batch's counters and (optionally) the ray statistics in one launch instead of three fills.
+__global__ void k_begin_frame(uint4* __restrict__ zero, size_t n_words, int tail_bytes, int* __restrict__ ctr, unsigned long long* __restrict__ stats) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) zero[i] = make_uint4(0u, 0u, 0u, 0u);
     if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < tail_bytes) ((unsigned char*)(zero + n_words))[threadIdx.x] = 0;      // < 16 bytes past the last word
         for (int i = threadIdx.x; i < RT_C_TOTAL; i += blockDim.x) ctr[i] = 0;
         if (stats) for (int i = threadIdx.x; i < RT_S_TOTAL; i += blockDim.x) stats[i] = 0ull;
     }
@@ -1079,9 +1091,11 @@ void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, s, sc, f, w, level);
 }
 
-void rt_launch_begin_frame(hipStream_t s, const DevWork& w, int n_slots, bool zero_stats) {
-    int grid = (n_slots + RT_BLOCK - 1) / RT_BLOCK; if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_begin_frame, dim3(grid), dim3(RT_BLOCK), 0, s, w.accum, n_slots, w.ctr, zero_stats ? w.stats : (unsigned long long*)nullptr);
+void rt_launch_begin_frame(hipStream_t s, const DevWork& w, void* zero, size_t zero_bytes, bool zero_stats) {
+    const size_t n_words = zero_bytes / 16;                 // `zero` is 16-byte aligned
+    size_t grid = (n_words + RT_BLOCK - 1) / RT_BLOCK; if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_begin_frame, dim3((unsigned)grid), dim3(RT_BLOCK), 0, s, (uint4*)zero, n_words, (int)(zero_bytes % 16), w.ctr,
+                       zero_stats ? w.stats : (unsigned long long*)nullptr);
 }
 
 void rt_launch_finalize(hipStream_t s, const DevFrame& f, const DevWork& w, unsigned char* out, int tile_major, int n_slots, int samples) {

@@ -82,6 +82,8 @@ struct DevFrame {
     // this batch
     int pix_begin, pix_count;      // range of local pixel slots (tile-major) covered by the batch
     int sample;                    // sample index s = (s_aa * dof_n + s_dof) * mb_n + s_mb
+    // frames of one sample per pixel in one batch write their pixels from the level-0 shading (no sums, no finalize)
+    unsigned char* direct_out; int direct_tile_major;
 };
 
 // ---- work buffers ---------------------------------------------------------------------------------------
@@ -131,7 +133,7 @@ static inline int rt_lds_prim_words(const DevScene& sc) {
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);
 void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid);
 void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);
-void rt_launch_begin_frame(hipStream_t s, const DevWork& w, int n_slots, bool zero_stats);
+void rt_launch_begin_frame(hipStream_t s, const DevWork& w, void* zero, size_t zero_bytes, bool zero_stats);
 void rt_launch_finalize(hipStream_t s, const DevFrame& f, const DevWork& w, unsigned char* out, int tile_major, int n_slots, int samples);
 void rt_launch_assemble(hipStream_t s, const unsigned char* tiles, int world, int max_tiles, int tiles_x, int tiles_y,
                         int width, int height, unsigned char* out);
