@@ -162,7 +162,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=2,
+    ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="contexts rendering consecutive frames concurrently on their own streams (1 = one frame at a time)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true",
@@ -199,9 +199,24 @@ def main():
             from raytracer_amd import scenegen as sg
             ls = api.ArrayScene(sg.random_prims(wl["n"], 42), (W, H))
     ls = rdist.broadcast_scene(ls, bool(cfg.bvh), 0, on_dev)
-    r = api.Renderer(local, workspace_bytes=16 << 30)
-    for kv in filter(None, os.environ.get("RT_BENCH_OPTS", "").split(",")):      # development: name=value library options
-        r.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    # Frames in flight: consecutive frames are independent, so P contexts (each with its own work buffers and stream)
+    # render them concurrently; a frame's small launches (deep recursion levels) then fill the other frames' gaps.
+    # Not used for frames of many batches, which keep the GPU busy on their own.  With three or more frames in flight
+    # the contexts do not fork their shadow launches onto second streams: the frames already overlap each other, and
+    # a process has only four hardware queues for all of its streams.
+    P = max(1, args.frames_in_flight) if cfg.samples_per_pixel() <= 64 else 1
+    if world > 1:
+        P = min(P, 2)                                 # the gather and the re-ordering need streams (hardware queues) too
+
+    def new_renderer():
+        rr = api.Renderer(local, workspace_bytes=16 << 30)
+        if P >= 3 or world > 1:
+            rr.set_option("overlap", 0)
+        for kv in filter(None, os.environ.get("RT_BENCH_OPTS", "").split(",")):      # development: name=value library options
+            rr.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+        return rr
+
+    r = new_renderer()
     r.upload(ls, with_bvh=bool(cfg.bvh))
     r.set_shard(rank, world)
     # Everything of a step runs on the context's own stream, which torch sees as an external stream (the RCCL gather
@@ -214,15 +229,9 @@ def main():
     block = torch.empty(r.out_bytes(), dtype=torch.uint8, device=dev)
     image = torch.empty(H * W * 3, dtype=torch.uint8, device=dev) if rank == 0 else None
 
-    # Frames in flight: consecutive frames are independent, so P contexts (each with its own work buffers and streams)
-    # render them concurrently; a frame's small launches (deep recursion levels) then fill the other frame's gaps.
-    # Not used for frames of many batches, which keep the GPU busy on their own.
-    P = max(1, args.frames_in_flight) if cfg.samples_per_pixel() <= 64 else 1
     ctxs = [(r, stream, block)]
     for _ in range(P - 1):
-        r2 = api.Renderer(local, workspace_bytes=16 << 30)
-        for kv in filter(None, os.environ.get("RT_BENCH_OPTS", "").split(",")):
-            r2.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+        r2 = new_renderer()
         r2.upload(ls, with_bvh=bool(cfg.bvh)); r2.set_shard(rank, world)
         s2 = torch.cuda.ExternalStream(r2.stream_handle(), device=dev)
         ctxs.append((r2, s2, torch.empty_like(block)))
@@ -234,7 +243,8 @@ def main():
     # frame k + 1.  Buffers are reused every other frame behind events; the timed region ends with a device-wide
     # synchronisation, so every frame's image has reached rank 0 inside it.
     pipelined = world > 1 and not staged
-    pipes = [rdist.FramePipeline(rr, cfg, rank, world, dev, ss) for rr, ss, _ in ctxs] if pipelined else None
+    asm_stream = torch.cuda.Stream(dev) if (pipelined and rank == 0) else None
+    pipes = [rdist.FramePipeline(rr, cfg, rank, world, dev, ss, asm_stream=asm_stream) for rr, ss, _ in ctxs] if pipelined else None
     frame_no = [0]
 
     def step():

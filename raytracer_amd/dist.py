@@ -102,7 +102,7 @@ class FramePipeline:
     a torch stream handed to renderer.set_stream beforehand).  `start_gather(block, out_or_None)` returns a handle whose wait() makes the current stream wait for the transfer
     (gather_blocks_async over RCCL; tests substitute device copies)."""
 
-    def __init__(self, renderer, cfg, rank: int, world: int, device, render_stream, start_gather=gather_blocks_async):
+    def __init__(self, renderer, cfg, rank: int, world: int, device, render_stream, start_gather=gather_blocks_async, asm_stream=None):
         self.r, self.cfg, self.rank, self.world = renderer, cfg, rank, world
         self.stream = render_stream
         self.start_gather = start_gather
@@ -110,7 +110,8 @@ class FramePipeline:
         self.blocks = [torch.empty(n, dtype=torch.uint8, device=device) for _ in range(2)]
         self.gathered = [torch.empty(world * n, dtype=torch.uint8, device=device) if rank == 0 else None for _ in range(2)]
         self.image = torch.empty(renderer.width * renderer.height * 3, dtype=torch.uint8, device=device) if rank == 0 else None
-        self.asm_stream = torch.cuda.Stream(device) if rank == 0 else None
+        # several pipelines of one process can share the re-ordering stream (every stream takes one of few hardware queues)
+        self.asm_stream = (asm_stream or torch.cuda.Stream(device)) if rank == 0 else None
         self.pending = [None, None]
         self.asm_done = [None, None]
         self.frame = 0

@@ -7,7 +7,7 @@ import torch
 import cases
 from raytracer_amd import api
 ap = argparse.ArgumentParser(); ap.add_argument("--world", type=int, default=1); ap.add_argument("--p", type=int, nargs="+", default=[1, 2, 3, 4])
-ap.add_argument("--ws", type=int, default=4); ap.add_argument("--setstream", action="store_true"); ap.add_argument("--stats", action="store_true"); ap.add_argument("--late", action="store_true"); ap.add_argument("--own", action="store_true")
+ap.add_argument("--ws", type=int, default=4); ap.add_argument("--setstream", action="store_true"); ap.add_argument("--stats", action="store_true"); ap.add_argument("--late", action="store_true"); ap.add_argument("--own", action="store_true"); ap.add_argument("--opt", default="")
 a = ap.parse_args()
 flags = ["-r", "-rd", "4", "-ss", "-sss", "16"]
 cfg, _ = api.parse_args(flags)
@@ -15,7 +15,9 @@ ls = api.LoadedScene(cases.reference_scene(1920, 1080), cfg, str(cases.TEXTURES)
 for P in a.p:
     rs, outs = [], []
     for k in range(P):
-        r = api.Renderer(0, a.ws << 30); r.upload(ls); r.set_shard(0, a.world)
+        r = api.Renderer(0, a.ws << 30)
+        for kv in filter(None, a.opt.split(',')): r.set_option(kv.split('=')[0], int(kv.split('=')[1]))
+        r.upload(ls); r.set_shard(0, a.world)
         if not a.own:
             s = torch.cuda.Stream(); r.set_stream(s.cuda_stream); r._s = s
         if a.setstream and k == 0 and not a.own: torch.cuda.set_stream(s)
