@@ -49,6 +49,17 @@ DEVI V3 cross(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b
 // raytracer.cpp:577-585: squares and their sum in double, double sqrt, length rounded to float, float divides
 DEVI float len_ref(V3 v) { return (float)sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z); }
 DEVI V3 normalise(V3 v) { float l = len_ref(v); return mk(v.x / l, v.y / l, v.z / l); }
+// Rays whose direction is drawn at random (soft-shadow samples) are judged by their distribution, not bit for bit:
+// their tests run the same algorithm with the same thresholds on the hardware's reciprocal / reciprocal square root
+// (1 ulp) instead of IEEE division and the double-precision length.  FAST = false is the reference's arithmetic.
+template <bool FAST> DEVI float qdiv(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+template <bool FAST> DEVI V3 normalise_q(V3 v) {
+    if (FAST) {
+        float l2 = dot(v, v);
+        if (l2 > 1e-30f && l2 < 1e30f) return v * __builtin_amdgcn_rsqf(l2);   // anything else takes the exact route
+    }
+    return normalise(v);
+}
 DEVI float lerp_ref(float a, float b, float t) { return a + t * (b - a); }                   // raytracer.cpp:671-673
 // std::pow(float,float) of the reference is glibc powf; a double-precision pow rounded once to float agrees
 // with it except where powf itself is not correctly rounded.
@@ -102,7 +113,7 @@ DEVI V3 cone_direction(V3 dir, float angle, uint32_t r0, uint32_t r1) {
 struct HitOut { V3 p, n; float u, v; int gid; };
 
 // sphere.cpp:118-174
-template <bool FULL>
+template <bool FULL, bool FAST = false>
 DEVI bool sphere_test(const float4* __restrict__ rec, const Ray& r, bool mb, bool want_uv, float& t_out, HitOut* h) {
     float4 w0 = rec[0], w1 = rec[1];
     V3 loc = mk(w0.x, w0.y, w0.z);
@@ -113,7 +124,7 @@ DEVI bool sphere_test(const float4* __restrict__ rec, const Ray& r, bool mb, boo
     if (tca < 0) return false;
     float d2 = l.x * l.x + l.y * l.y + l.z * l.z - tca * tca;
     if (d2 > radius * radius) return false;
-    float thc = sqrtf(radius * radius - d2);
+    float thc = FAST ? __builtin_amdgcn_sqrtf(radius * radius - d2) : sqrtf(radius * radius - d2);
     float t0 = tca - thc, t1 = tca + thc;
     float t = (t0 > 0) ? t0 : t1;
     if (t < 0) return false;
@@ -149,7 +160,7 @@ DEVI V3 rot_inv(V3 v, float4 w4, float4 w5) {
 }
 
 // cube.cpp:126-292
-template <bool FULL>
+template <bool FULL, bool FAST = false>
 DEVI bool cube_test(const float4* __restrict__ rec, const Ray& r, bool mb, bool want_uv, float& t_out, HitOut* h) {
     float4 w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3], w4 = rec[4], w5 = rec[5];
     V3 loc = mk(w0.x, w0.y, w0.z);
@@ -170,7 +181,7 @@ DEVI bool cube_test(const float4* __restrict__ rec, const Ray& r, bool mb, bool 
     V3 o = rot_inv(r.o - loc, w4, w5);
     V3 d = rot_inv(r.d, w4, w5);
     V3 lo = o * inv;
-    V3 ld = normalise(d * inv);
+    V3 ld = normalise_q<FAST>(d * inv);
     float tmin = -INFINITY, tmax = INFINITY;
     {
         float lov[3] = { lo.x, lo.y, lo.z }, ldv[3] = { ld.x, ld.y, ld.z };
@@ -179,8 +190,9 @@ DEVI bool cube_test(const float4* __restrict__ rec, const Ray& r, bool mb, bool 
             if (fabsf(ldv[i]) < 1e-5f) {
                 if (lov[i] < -1.0f || lov[i] > 1.0f) return false;
             } else {
-                float t1 = (-1.0f - lov[i]) / ldv[i];
-                float t2 = (1.0f - lov[i]) / ldv[i];
+                float t1, t2;
+                if (FAST) { float rc = __builtin_amdgcn_rcpf(ldv[i]); t1 = (-1.0f - lov[i]) * rc; t2 = (1.0f - lov[i]) * rc; }
+                else { t1 = (-1.0f - lov[i]) / ldv[i]; t2 = (1.0f - lov[i]) / ldv[i]; }
                 if (t1 > t2) { float tt = t1; t1 = t2; t2 = tt; }
                 tmin = smax(tmin, t1);
                 tmax = smin(tmax, t2);
@@ -235,13 +247,13 @@ DEVI bool cube_test(const float4* __restrict__ rec, const Ray& r, bool mb, bool 
 
 // plane.cpp:143-251.  The polygon's vertices were winding-sorted once on the host (the reference re-sorts them
 // on every call with the same result); the vertex used for the plane offset is the one stored in the record.
-template <bool FULL>
+template <bool FULL, bool FAST = false>
 DEVI bool plane_test(const float4* __restrict__ rec, const float4* __restrict__ verts, const float4* __restrict__ plane_uv,
                      const Ray& r, bool want_uv, float& t_out, HitOut* h) {
     float4 w0 = rec[0], w1 = rec[1];
     float denom = w0.x * r.d.x + w0.y * r.d.y + w0.z * r.d.z;
     if ((double)fabsf(denom) < 1e-10) return false;
-    float t = (w0.x * (w1.x - r.o.x) + w0.y * (w1.y - r.o.y) + w0.z * (w1.z - r.o.z)) / denom;
+    float t = qdiv<FAST>(w0.x * (w1.x - r.o.x) + w0.y * (w1.y - r.o.y) + w0.z * (w1.z - r.o.z), denom);
     if (t < 0) return false;
     V3 ip = mk(r.o.x + t * r.d.x, r.o.y + t * r.d.y, r.o.z + t * r.d.z);
     int first = f2i(w0.w), packed = f2i(w1.w);
@@ -257,7 +269,7 @@ DEVI bool plane_test(const float4* __restrict__ rec, const float4* __restrict__ 
         vj = vi;
         if (fabsf(Pjy - Piy) < 1e-8f) continue;
         if ((Piy > Py) != (Pjy > Py)) {
-            float slope = (Pjx - Pix) / (Pjy - Piy);
+            float slope = qdiv<FAST>(Pjx - Pix, Pjy - Piy);
             float xi = slope * (Py - Piy) + Pix;
             if (Px < xi) inside = !inside;
         }
@@ -319,30 +331,32 @@ struct Best { float t; int cls; int idx; int fileset; };
 
 // Closest hit over ranges of one primitive set, planes then cubes then spheres, strict '<' (first wins ties).
 // leaf_rule: bvh.cpp:65-95 (start at +inf, require rayDistance >= 0); otherwise raytracer.cpp:202-247 (start at FLT_MAX).
-template <bool ANY>
+// stop_below: the caller only asks whether the closest distance is below this value (soft shadows compare it with the
+// distance to the light sample), so the search ends at the first candidate that is; -inf = full search.
+template <bool ANY, bool FAST>
 DEVI bool test_prims(const DevPrimSet& S, const Ray& r, bool mb, int p0, int pn, int c0, int cn, int s0, int sn,
-                     bool leaf_rule, Best& best) {
+                     bool leaf_rule, float stop_below, Best& best) {
     float closest = leaf_rule ? INFINITY : FLT_MAX;
     bool hit = false;
     for (int i = p0; i < p0 + pn; ++i) {
         float t;
-        if (plane_test<false>(S.planes + 3 * i, S.verts, nullptr, r, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
+        if (plane_test<false, FAST>(S.planes + 3 * i, S.verts, nullptr, r, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
             hit = true; closest = t; best.t = t; best.cls = 0; best.idx = i;
-            if (ANY) return true;
+            if (ANY || t < stop_below) return true;
         }
     }
     for (int i = c0; i < c0 + cn; ++i) {
         float t;
-        if (cube_test<false>(S.cubes + 6 * i, r, mb, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
+        if (cube_test<false, FAST>(S.cubes + 6 * i, r, mb, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
             hit = true; closest = t; best.t = t; best.cls = 1; best.idx = i;
-            if (ANY) return true;
+            if (ANY || t < stop_below) return true;
         }
     }
     for (int i = s0; i < s0 + sn; ++i) {
         float t;
-        if (sphere_test<false>(S.spheres + 2 * i, r, mb, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
+        if (sphere_test<false, FAST>(S.spheres + 2 * i, r, mb, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
             hit = true; closest = t; best.t = t; best.cls = 2; best.idx = i;
-            if (ANY) return true;
+            if (ANY || t < stop_below) return true;
         }
     }
     return hit;
@@ -395,9 +409,9 @@ DEVI SubRay make_sub_ray(const DevScene& sc, const Ray& r) {
     return q;
 }
 
-template <bool ANY>
+template <bool ANY, bool FAST>
 DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, const Ray& r, const SubRay& q, bool mb, bool leaf_rule,
-                    int* __restrict__ stack, Best& best) {
+                    float stop_below, int* __restrict__ stack, Best& best) {
     float best_t = leaf_rule ? INFINITY : FLT_MAX;
     unsigned best_key = 0u; bool has = false;
     int sp = 0, node = root;
@@ -421,12 +435,12 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, const Ray
                     const unsigned entry = (unsigned)sc.sub_entries[e];
                     const int cls = (int)(entry >> 30), idx = (int)(entry & 0x3fffffffu);
                     float t; bool ok;
-                    if (cls == 0) ok = plane_test<false>(S.planes + 3 * idx, S.verts, nullptr, r, false, t, nullptr);
-                    else if (cls == 1) ok = cube_test<false>(S.cubes + 6 * idx, r, mb, false, t, nullptr);
-                    else ok = sphere_test<false>(S.spheres + 2 * idx, r, mb, false, t, nullptr);
+                    if (cls == 0) ok = plane_test<false, FAST>(S.planes + 3 * idx, S.verts, nullptr, r, false, t, nullptr);
+                    else if (cls == 1) ok = cube_test<false, FAST>(S.cubes + 6 * idx, r, mb, false, t, nullptr);
+                    else ok = sphere_test<false, FAST>(S.spheres + 2 * idx, r, mb, false, t, nullptr);
                     if (ok && (!leaf_rule || t >= 0.0f) && (t < best_t || (has && t == best_t && entry < best_key))) {
                         has = true; best_t = t; best_key = entry; best.t = t; best.cls = cls; best.idx = idx;
-                        if (ANY) return true;
+                        if (ANY || t < stop_below) return true;
                     }
                 }
             }
@@ -448,11 +462,11 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, const Ray
 
 // Closest hit of a group of primitives: through its second-level hierarchy when it has one, else one by one.
 // SUB = the scene has at least one second-level hierarchy (kernels for small scenes are compiled without that code).
-template <bool ANY, bool SUB>
+template <bool ANY, bool SUB, bool FAST>
 DEVI bool test_group(const DevScene& sc, const DevPrimSet& S, const Ray& r, const SubRay& q, bool mb, int p0, int pn, int c0, int cn, int s0, int sn,
-                     int sub_root, bool leaf_rule, int* __restrict__ stack, Best& best) {
-    if (SUB && sub_root >= 0) return sub_trace<ANY>(sc, S, sub_root, r, q, mb, leaf_rule, stack, best);
-    return test_prims<ANY>(S, r, mb, p0, pn, c0, cn, s0, sn, leaf_rule, best);
+                     int sub_root, bool leaf_rule, float stop_below, int* __restrict__ stack, Best& best) {
+    if (SUB && sub_root >= 0) return sub_trace<ANY, FAST>(sc, S, sub_root, r, q, mb, leaf_rule, stop_below, stack, best);
+    return test_prims<ANY, FAST>(S, r, mb, p0, pn, c0, cn, s0, sn, leaf_rule, stop_below, best);
 }
 
 // BVHNode::intersect (bvh.cpp:35-105) or Raytracer::unacceleratedIntersection (raytracer.cpp:202-256).
@@ -460,9 +474,11 @@ DEVI bool test_group(const DevScene& sc, const DevPrimSet& S, const Ray& r, cons
 // walking the nodes right child first and stopping at the first leaf that yields a hit gives the same answer.
 // The node array is laid out in that order with skip links, so the walk needs no stack.
 // with_fallback: raytracer.cpp:424,484 - a secondary ray that misses the BVH is retried over every primitive.
-template <bool ANY, bool SUB>
+// stop_below (see test_prims) ends the search inside the one group whose result the reference would return: a leaf
+// that yields any hit ends the reference's walk too, so nothing is skipped that could change "closest < stop_below".
+template <bool ANY, bool SUB, bool FAST = false>
 DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict__ nodes, const int4* __restrict__ leaves,
-                int* __restrict__ stack, const Ray& r, bool with_fallback, Best& best) {
+                int* __restrict__ stack, const Ray& r, bool with_fallback, Best& best, float stop_below = -INFINITY) {
     const bool mb = f.motion_blur != 0;
     SubRay q; q.om = q.op = q.rcp = mk(0.0f, 0.0f, 0.0f);
     if (SUB) q = make_sub_ray(sc, r);
@@ -480,17 +496,17 @@ DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict_
             ++i;
             if (leaf >= 0) {
                 int4 l0 = leaves[2 * leaf], l1 = leaves[2 * leaf + 1];
-                if (test_group<ANY, SUB>(sc, sc.leafset, r, q, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, true, stack, best)) { best.fileset = 0; return true; }
+                if (test_group<ANY, SUB, FAST>(sc, sc.leafset, r, q, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, true, stop_below, stack, best)) { best.fileset = 0; return true; }
             }
         }
         if (!with_fallback) return false;
         best.fileset = 1;
-        return test_group<false, SUB>(sc, sc.fileset, r, q, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
-                                 sc.file_sub_root, false, stack, best);
+        return test_group<false, SUB, FAST>(sc, sc.fileset, r, q, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
+                                 sc.file_sub_root, false, stop_below, stack, best);
     }
     best.fileset = 1;
-    return test_group<ANY, SUB>(sc, sc.fileset, r, q, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
-                           sc.file_sub_root, false, stack, best);
+    return test_group<ANY, SUB, FAST>(sc, sc.fileset, r, q, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
+                           sc.file_sub_root, false, stop_below, stack, best);
 }
 
 DEVI void full_hit(const DevScene& sc, const DevFrame& f, const Ray& r, const Best& best, HitOut& h) {
@@ -790,7 +806,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
 // blocks.  Soft shadows (raytracer.cpp:534-571): ss_samples rays to points in a ball around the light, blocked
 // when the reported hit is nearer than the sampled point.  Output = number of unblocked samples per (hit, light).
 // ---------------------------------------------------------------------------------------------------------
-template <bool SUB, bool LDSP>
+template <bool SUB, bool LDSP, bool FAST>
 __global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene sc_arg, DevFrame f, DevWork w, int lv_begin, int lv_end) {
     extern __shared__ float4 s_mem[];
     DevScene sc = sc_arg;
@@ -857,12 +873,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene s
                 V3 jit = unit_sphere(u01(q.x), u01(q.y), u01(q.z)) * f.light_radius;
                 V3 lp = mk(lt.x + jit.x, lt.y + jit.y, lt.z + jit.z);
                 V3 h2l = lp - p;
-                V3 ld = normalise(h2l);
+                V3 ld; float lightDist;                                  // raytracer.cpp:547,553: unit direction and distance
+                const float l2 = dot(h2l, h2l);
+                if (FAST && l2 > 1e-30f && l2 < 1e30f) { float rs = __builtin_amdgcn_rsqf(l2); ld = h2l * rs; lightDist = l2 * rs; }
+                else { ld = normalise(h2l); lightDist = len_ref(h2l); }
                 sr.o = p + ld * 0.001f;                                  // raytracer.cpp:549
                 sr.d = ld;
-                float lightDist = len_ref(h2l);                          // raytracer.cpp:553
-                bool hit = trace<false, SUB>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
-                unblocked = !(hit && best.t < lightDist);                // raytracer.cpp:564
+                // only "closest reported distance < lightDist" is asked for (raytracer.cpp:564)
+                bool hit = trace<false, SUB, FAST>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best, lightDist);
+                unblocked = !(hit && best.t < lightDist);
             }
         }
         if (grouped) {
@@ -1082,9 +1101,15 @@ void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, cons
 }
 
 void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid) {
-    if (sc.sub_nodes) hipLaunchKernelGGL((k_shadow<true, false>), dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w, lv_begin, lv_end);
-    else if (sc.lds_prims) hipLaunchKernelGGL((k_shadow<false, true>), dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w, lv_begin, lv_end);
-    else hipLaunchKernelGGL((k_shadow<false, false>), dim3(grid), dim3(RT_BLOCK), bvh_lds_bytes(sc, f), s, sc, f, w, lv_begin, lv_end);
+    const size_t lds = bvh_lds_bytes(sc, f);
+    const bool fast = f.soft_shadows && f.fast_samples;              // hard shadows are deterministic: always exact
+#define RT_SHADOW_LAUNCH(SUB, LDSP) \
+    do { if (fast) hipLaunchKernelGGL((k_shadow<SUB, LDSP, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); \
+         else hipLaunchKernelGGL((k_shadow<SUB, LDSP, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); } while (0)
+    if (sc.sub_nodes) RT_SHADOW_LAUNCH(true, false);
+    else if (sc.lds_prims) RT_SHADOW_LAUNCH(false, true);
+    else RT_SHADOW_LAUNCH(false, false);
+#undef RT_SHADOW_LAUNCH
 }
 
 void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {

@@ -76,6 +76,7 @@ struct DevFrame {
     int textures, use_bvh, fallback_full, motion_blur, max_depth;
     float light_radius;
     uint32_t seed;
+    int fast_samples;              // randomly drawn shadow rays use reciprocal arithmetic (distribution-level parity)
     // sharding
     int tiles_x, tiles_y, n_local_tiles;
     const int* local_tiles;        // global tile ids rendered by this rank, ascending

@@ -206,6 +206,32 @@ def test_lds_resident_primitive_records_change_nothing(scene, flags, textures_di
         assert np.array_equal(img, got[0][0]) and counts == got[0][1]
 
 
+@pytest.mark.parametrize("scene,n,flags", [("ref", 0, ["-r", "-rd", "3", "-ss", "-sss", "16"]), ("ref", 0, ["-ss", "-sss", "5", "-u"]),
+                                           ("dof", 0, ["-ss", "-sss", "8", "-rd", "2", "-grs", "1"]),
+                                           ("random", 20000, ["-ss", "-sss", "4"]), ("random", 20000, ["-ss", "-sss", "4", "-u"])])
+def test_reciprocal_arithmetic_on_shadow_samples_moves_almost_no_sample(scene, n, flags, textures_dir):
+    """Soft-shadow sample rays are drawn at random, so their tests may run on the hardware's reciprocals (the default)
+    instead of IEEE division: same rays, same thresholds, and a decision can only flip for a ray within rounding of a
+    primitive's silhouette.  Against the exact arithmetic: same ray counts, and all but a handful of pixels identical."""
+    cfg, _ = api.parse_args(flags)
+    cfg.seed = 11
+    if scene == "random":
+        ls = api.ArrayScene(sg.random_prims(n, 3, transparent_frac=0.1), (640, 360))
+    else:
+        ls = api.LoadedScene(cases.reference_scene(480, 270) if scene == "ref" else cases.blend_scene(scene, 480, 270), cfg, textures_dir)
+    got = []
+    for fast in (1, 0):
+        r = api.Renderer(0); r.set_option("fast_samples", fast); r.upload(ls, with_bvh=bool(cfg.bvh))
+        img, st = r.render(cfg)
+        got.append((img.astype(np.int32), (st.shadow_rays, st.reflection_rays, st.refraction_rays, st.nodes_shaded)))
+        r.close()
+    ls.close()
+    assert got[0][0].max() > 0 and got[0][1] == got[1][1]
+    diff = np.abs(got[0][0] - got[1][0]).max(axis=-1)
+    assert (diff > 0).sum() <= max(3, 1e-3 * diff.size), f"{(diff > 0).sum()} pixels differ"
+    assert psnr(got[0][0], got[1][0]) > 55.0
+
+
 # ---- large scenes: the second-level hierarchy ----------------------------------------------------------------
 
 @pytest.mark.parametrize("n,res,flags", [(20000, (960, 540), []), (20000, (960, 540), ["-u"]),
