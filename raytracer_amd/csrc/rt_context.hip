@@ -190,6 +190,7 @@ struct rt_ctx {
     std::vector<float4> h_sub_nodes_file; std::vector<int> h_sub_entries_file;
     int file_sub_root = -1;
     int sub_min_group = RT_SUB_MIN_GROUP;    // groups above this size get a second-level hierarchy (rt_set_option)
+    int max_grid = 2048;                     // 256 CUs x 8 workgroups: enough to fill the chip
     bool fast_samples = true;                // soft-shadow sample rays: hardware reciprocals instead of IEEE division
     int lds_prims = 1;                       // tiny scenes: primitive records in LDS; 1 = shadow kernel only, 2 = extend too
     int device_build = 1;                    // hierarchies and leaf-order records are made on the GPU (rt_set_option)
@@ -325,6 +326,10 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "lds_prims") == 0) { c->lds_prims = (int)value; return RT_OK; }
     if (std::strcmp(name, "device_build") == 0) { c->device_build = value != 0; return RT_OK; }
     if (std::strcmp(name, "graphs") == 0) { c->use_graphs = value != 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "max_grid") == 0) {
+        if (value < 1 || value > (1 << 20)) return c->fail(RT_ERR_ARG, "max_grid must be 1..%d", 1 << 20);
+        c->max_grid = (int)value; c->drop_graphs(); return RT_OK;
+    }
     if (std::strcmp(name, "fast_samples") == 0) { c->fast_samples = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "overlap") == 0) { c->overlap = value != 0; c->drop_graphs(); return RT_OK; }
     return c->fail(RT_ERR_ARG, "unknown option %s", name);
@@ -916,7 +921,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     if (direct) rt_launch_begin_frame(s, w, out_dev, out_bytes, want_stats_zero);
     else rt_launch_begin_frame(s, w, c->accum.p, (size_t)n_slots * sizeof(float4), want_stats_zero);
 
-    const int max_grid = 2048;       // 256 CUs x 8 workgroups: enough to fill the chip, grid-stride beyond that
+    const int max_grid = c->max_grid;        // workgroups per launch; grid-stride beyond that
     unsigned long long batches = 0;
     StageTimer local_tm; if (!tm) { tm = &local_tm; tm->pool = &c->event_pool; }
     tm->s = s;

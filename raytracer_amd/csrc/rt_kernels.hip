@@ -22,8 +22,9 @@
 #define RT_EXTEND_WAVES_SUB 4       // the hierarchy walk is latency-bound: a fourth wavefront beats the spills it costs
 #endif
 #ifndef RT_SHADOW_WAVES
-#define RT_SHADOW_WAVES 4
+#define RT_SHADOW_WAVES 5           // each mode's kernel fits 96 registers without spilling
 #endif
+#define RT_SHADOW_WAVES_SUB 4
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -806,8 +807,10 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
 // blocks.  Soft shadows (raytracer.cpp:534-571): ss_samples rays to points in a ball around the light, blocked
 // when the reported hit is nearer than the sampled point.  Output = number of unblocked samples per (hit, light).
 // ---------------------------------------------------------------------------------------------------------
-template <bool SUB, bool LDSP, bool FAST>
-__global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene sc_arg, DevFrame f, DevWork w, int lv_begin, int lv_end) {
+// MODE: 0 = hard shadows, 1 = soft shadows in the reference's arithmetic, 2 = soft shadows on reciprocals (separate
+// kernels: each needs fewer registers than one kernel holding both searches, which decides how many wavefronts fit)
+template <bool SUB, bool LDSP, int MODE>
+__global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAVES) void k_shadow(DevScene sc_arg, DevFrame f, DevWork w, int lv_begin, int lv_end) {
     extern __shared__ float4 s_mem[];
     DevScene sc = sc_arg;
     float4* s_nodes = s_mem;
@@ -829,7 +832,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene s
     __syncthreads();
     const int n_nodes = s_first[f.max_depth + 1];
     const int L = sc.n_lights;
-    const int SS = f.soft_shadows ? f.ss_samples : 1;
+    constexpr bool FAST = MODE == 2;
+    const int SS = MODE ? f.ss_samples : 1;
     const unsigned per = (unsigned)(L * SS);
     const unsigned count = (unsigned)n_nodes * per;                      // the host keeps hits x lights x samples below 2^31
     if (blockIdx.x * blockDim.x >= count) return;
@@ -862,7 +866,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADOW_WAVES) void k_shadow(DevScene s
             Ray sr; sr.time = a.w;
             Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
             ++n_rays;
-            if (!f.soft_shadows) {
+            if (MODE == 0) {
                 V3 nrm = mk(b.x, b.y, b.z);
                 sr.d = normalise(mk(lt.x - p.x, lt.y - p.y, lt.z - p.z));
                 sr.o = p + nrm * 1e-2f;                                  // raytracer.cpp:515: unflipped geometric normal
@@ -1102,10 +1106,11 @@ void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, cons
 
 void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid) {
     const size_t lds = bvh_lds_bytes(sc, f);
-    const bool fast = f.soft_shadows && f.fast_samples;              // hard shadows are deterministic: always exact
+    const int mode = !f.soft_shadows ? 0 : (f.fast_samples ? 2 : 1);  // hard shadows are deterministic: always exact
 #define RT_SHADOW_LAUNCH(SUB, LDSP) \
-    do { if (fast) hipLaunchKernelGGL((k_shadow<SUB, LDSP, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); \
-         else hipLaunchKernelGGL((k_shadow<SUB, LDSP, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); } while (0)
+    do { if (mode == 2) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 2>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); \
+         else if (mode == 1) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 1>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); \
+         else hipLaunchKernelGGL((k_shadow<SUB, LDSP, 0>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); } while (0)
     if (sc.sub_nodes) RT_SHADOW_LAUNCH(true, false);
     else if (sc.lds_prims) RT_SHADOW_LAUNCH(false, true);
     else RT_SHADOW_LAUNCH(false, false);
