@@ -10,6 +10,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <limits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -182,6 +183,7 @@ struct rt_ctx {
     rt_camera camera{};
     int np = 0, nc = 0, ns = 0;              // planes, cubes, spheres of the uploaded scene
     std::vector<float4> h_verts_sorted;      // device layout, indexed by first_vert + k
+    std::vector<float4> h_edges;             // crossing-test constants of the edge that ends in each vertex
     std::vector<float4> h_file_planes, h_file_cubes, h_file_spheres;
     int n_lights = 0;
     bool any_reflective = false, any_transparent = false;
@@ -202,7 +204,7 @@ struct rt_ctx {
     DevBuf<int> d_sub_entries_file, d_sub_entries, d_prim_ids;
 
     // device scene
-    DevBuf<float4> d_nodes, d_mats, d_plane_uv, d_texels, d_lights, d_verts;
+    DevBuf<float4> d_nodes, d_mats, d_plane_uv, d_texels, d_lights, d_verts, d_edges;
     DevBuf<int4> d_leaves, d_tex_desc;
     DevBuf<float4> d_file_planes, d_file_cubes, d_file_spheres, d_leaf_planes, d_leaf_cubes, d_leaf_spheres;
     DevScene scene{};
@@ -295,7 +297,7 @@ void rt_destroy(rt_ctx* c) {
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    DevBuf<float4>* f4s[] = { &c->d_nodes, &c->d_mats, &c->d_plane_uv, &c->d_texels, &c->d_lights, &c->d_verts, &c->d_file_planes,
+    DevBuf<float4>* f4s[] = { &c->d_nodes, &c->d_mats, &c->d_plane_uv, &c->d_texels, &c->d_lights, &c->d_verts, &c->d_edges, &c->d_file_planes,
                               &c->d_file_cubes, &c->d_file_spheres, &c->d_leaf_planes, &c->d_leaf_cubes, &c->d_leaf_spheres,
                               &c->q_a[0], &c->q_a[1], &c->q_b[0], &c->q_b[1], &c->n_a, &c->n_b, &c->n_c, &c->n_col, &c->accum };
     for (auto* b : f4s) b->release();
@@ -399,6 +401,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
     }
     // planes: winding-sorted vertices, projection axis, texture axes
     c->h_verts_sorted.assign((size_t)sc->n_plane_verts, f4(0, 0, 0, 0));
+    c->h_edges.assign((size_t)sc->n_plane_verts, f4(0, 0, 0, 0));
     c->h_file_planes.assign((size_t)np * 3, f4(0, 0, 0, 0));
     std::vector<float4> plane_uv((size_t)np * 3, f4(0, 0, 0, 0));
     rt_parallel_for((size_t)np, 2048, [&](size_t lo, size_t hi, int) {
@@ -434,6 +437,17 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
             for (int k = 0; k < p.n_verts; ++k) {
                 float4& q = c->h_verts_sorted[(size_t)p.first_vert + k];
                 if (drop == 0) q = f4(q.y, q.z, q.x, 0.0f); else if (drop == 1) q = f4(q.x, q.z, q.y, 0.0f);
+            }
+            // plane.cpp:228-245: the even-odd test divides (Pj.x - Pi.x) by (Pj.y - Pi.y) for every edge and every ray.
+            // The quotient depends on the polygon alone and IEEE division rounds the same here as on the device, so
+            // it is formed once; an edge the reference skips (|Pj.y - Pi.y| < 1e-8) carries NaN, which fails the
+            // final comparison exactly like the skip.
+            for (int k = 0; k < p.n_verts; ++k) {
+                const float4 vi = c->h_verts_sorted[(size_t)p.first_vert + k];
+                const float4 vj = c->h_verts_sorted[(size_t)p.first_vert + (k + p.n_verts - 1) % p.n_verts];
+                const float dy = vj.y - vi.y;
+                const float slope = std::fabs(dy) < 1e-8f ? std::numeric_limits<float>::quiet_NaN() : (vj.x - vi.x) / dy;
+                c->h_edges[(size_t)p.first_vert + k] = f4(vi.x, vi.y, vj.y, slope);
             }
         }
     });
@@ -487,6 +501,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
     RT_HIP(c, c->d_mats.upload(mats, s));
     RT_HIP(c, c->d_plane_uv.upload(plane_uv, s));
     RT_HIP(c, c->d_verts.upload(c->h_verts_sorted, s));
+    RT_HIP(c, c->d_edges.upload(c->h_edges, s));
     RT_HIP(c, c->d_file_planes.upload(c->h_file_planes, s));
     RT_HIP(c, c->d_file_cubes.upload(c->h_file_cubes, s));
     RT_HIP(c, c->d_file_spheres.upload(c->h_file_spheres, s));
@@ -497,7 +512,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
 
     DevScene& d = c->scene;
     std::memset(&d, 0, sizeof d);
-    d.fileset.planes = c->d_file_planes.p; d.fileset.verts = c->d_verts.p; d.fileset.cubes = c->d_file_cubes.p;
+    d.fileset.planes = c->d_file_planes.p; d.fileset.verts = c->d_verts.p; d.fileset.edges = c->d_edges.p; d.fileset.cubes = c->d_file_cubes.p;
     d.fileset.spheres = c->d_file_spheres.p; d.fileset.n_planes = np; d.fileset.n_cubes = nc; d.fileset.n_spheres = ns;
     d.leafset = d.fileset;
 
@@ -533,7 +548,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
         c->file_sub_root = 0;
         // the host copies of the records are only needed by the host build
         std::vector<float4>().swap(c->h_file_planes); std::vector<float4>().swap(c->h_file_cubes);
-        std::vector<float4>().swap(c->h_file_spheres); std::vector<float4>().swap(c->h_verts_sorted);
+        std::vector<float4>().swap(c->h_file_spheres); std::vector<float4>().swap(c->h_verts_sorted); std::vector<float4>().swap(c->h_edges);
     } else {
         c->tb_planes.resize((size_t)np); c->tb_cubes.resize((size_t)nc); c->tb_spheres.resize((size_t)ns);
         for (int i = 0; i < np; ++i) { c->tb_planes[i] = true_box(sc->planes[i], sc->plane_verts); all.add(c->tb_planes[i]); }

@@ -205,6 +205,12 @@ DEVI bool cube_test(const float4* __restrict__ rec, const Ray& r, bool mb, bool 
     float t = -1.0f;
     if (tmin > T_EPS) t = tmin; else if (tmax > T_EPS) t = tmax;
     if (t < 0.0f) return false;
+    if (FAST && !FULL) {
+        // the hit point's distance along a unit-length ray: the local parameter times the cube's size (the
+        // rotation keeps lengths), which is what the reference's dot product below evaluates to up to rounding
+        t_out = smax(t * fabsf(scale), 1e-4f);
+        return true;
+    }
     V3 hl = mk(lo.x + ld.x * t, lo.y + ld.y * t, lo.z + ld.z * t);
     V3 hw = rot_fwd(hl * scale, w2, w3) + loc;
     float worldT = dot(hw - r.o, r.d);
@@ -249,7 +255,7 @@ DEVI bool cube_test(const float4* __restrict__ rec, const Ray& r, bool mb, bool 
 // plane.cpp:143-251.  The polygon's vertices were winding-sorted once on the host (the reference re-sorts them
 // on every call with the same result); the vertex used for the plane offset is the one stored in the record.
 template <bool FULL, bool FAST = false>
-DEVI bool plane_test(const float4* __restrict__ rec, const float4* __restrict__ verts, const float4* __restrict__ plane_uv,
+DEVI bool plane_test(const float4* __restrict__ rec, const float4* __restrict__ edges, const float4* __restrict__ plane_uv,
                      const Ray& r, bool want_uv, float& t_out, HitOut* h) {
     float4 w0 = rec[0], w1 = rec[1];
     float denom = w0.x * r.d.x + w0.y * r.d.y + w0.z * r.d.z;
@@ -262,16 +268,13 @@ DEVI bool plane_test(const float4* __restrict__ rec, const float4* __restrict__ 
     // plane.cpp:205-251: even-odd crossing test in the projection that drops the dominant normal axis
     float Px = (drop == 0) ? ip.y : ip.x;
     float Py = (drop == 2) ? ip.y : ip.z;
+    // one record per edge (vertex i and its predecessor j): (Pi.x, Pi.y, Pj.y, (Pj.x - Pi.x) / (Pj.y - Pi.y)), the
+    // quotient formed on the host with the same IEEE division; NaN marks an edge the reference skips
     bool inside = false;
-    float4 vj = verts[first + n - 1];                                    // vertices are stored already projected
     for (int i = 0; i < n; ++i) {
-        float4 vi = verts[first + i];
-        float Pix = vi.x, Piy = vi.y, Pjx = vj.x, Pjy = vj.y;
-        vj = vi;
-        if (fabsf(Pjy - Piy) < 1e-8f) continue;
-        if ((Piy > Py) != (Pjy > Py)) {
-            float slope = qdiv<FAST>(Pjx - Pix, Pjy - Piy);
-            float xi = slope * (Py - Piy) + Pix;
+        const float4 e = edges[first + i];
+        if ((e.y > Py) != (e.z > Py)) {
+            float xi = e.w * (Py - e.y) + e.x;
             if (Px < xi) inside = !inside;
         }
     }
@@ -312,7 +315,16 @@ DEVI bool slab_exact(const Ray& r, float4 a, float4 b) {
 // Same decision as slab_exact at a third of the instructions: quotients by reciprocal-multiply (each within
 // 2.5 ulp of the correctly rounded quotient), the decision taken only when the two bounds are further apart than
 // that error allows; anything closer, and any zero / denormal / huge / NaN direction component, goes to slab_exact.
+template <bool FAST>
 DEVI bool slab(const Ray& r, float4 a, float4 b, V3 rcp, bool fast_ok) {
+    if (FAST) {                                      // randomly drawn rays: the reciprocal-multiply decision stands
+        float x0 = (a.x - r.o.x) * rcp.x, x1 = (b.x - r.o.x) * rcp.x;
+        float y0 = (a.y - r.o.y) * rcp.y, y1 = (b.y - r.o.y) * rcp.y;
+        float z0 = (a.z - r.o.z) * rcp.z, z1 = (b.z - r.o.z) * rcp.z;
+        float tMin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        float tMax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        return tMin <= tMax;
+    }
     if (fast_ok) {
         float x0 = (a.x - r.o.x) * rcp.x, x1 = (b.x - r.o.x) * rcp.x;
         float y0 = (a.y - r.o.y) * rcp.y, y1 = (b.y - r.o.y) * rcp.y;
@@ -341,7 +353,7 @@ DEVI bool test_prims(const DevPrimSet& S, const Ray& r, bool mb, int p0, int pn,
     bool hit = false;
     for (int i = p0; i < p0 + pn; ++i) {
         float t;
-        if (plane_test<false, FAST>(S.planes + 3 * i, S.verts, nullptr, r, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
+        if (plane_test<false, FAST>(S.planes + 3 * i, S.edges, nullptr, r, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
             hit = true; closest = t; best.t = t; best.cls = 0; best.idx = i;
             if (ANY || t < stop_below) return true;
         }
@@ -436,7 +448,7 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, const Ray
                     const unsigned entry = (unsigned)sc.sub_entries[e];
                     const int cls = (int)(entry >> 30), idx = (int)(entry & 0x3fffffffu);
                     float t; bool ok;
-                    if (cls == 0) ok = plane_test<false, FAST>(S.planes + 3 * idx, S.verts, nullptr, r, false, t, nullptr);
+                    if (cls == 0) ok = plane_test<false, FAST>(S.planes + 3 * idx, S.edges, nullptr, r, false, t, nullptr);
                     else if (cls == 1) ok = cube_test<false, FAST>(S.cubes + 6 * idx, r, mb, false, t, nullptr);
                     else ok = sphere_test<false, FAST>(S.spheres + 2 * idx, r, mb, false, t, nullptr);
                     if (ok && (!leaf_rule || t >= 0.0f) && (t < best_t || (has && t == best_t && entry < best_key))) {
@@ -492,7 +504,7 @@ DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict_
         const V3 rcp = mk(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
         while (i < n) {
             float4 a = nodes[2 * i], b = nodes[2 * i + 1];
-            if (!slab(r, a, b, rcp, fast_ok)) { i = f2i(a.w); continue; }
+            if (!slab<FAST>(r, a, b, rcp, fast_ok)) { i = f2i(a.w); continue; }
             int leaf = f2i(b.w);
             ++i;
             if (leaf >= 0) {
@@ -518,7 +530,7 @@ DEVI void full_hit(const DevScene& sc, const DevFrame& f, const Ray& r, const Be
     if (best.cls == 0) {
         int gid = f2i(S.planes[3 * best.idx + 2].x);
         bool uv = f.textures && f2i(sc.mats[3 * gid + 2].y) >= 0;
-        plane_test<true>(S.planes + 3 * best.idx, S.verts, sc.plane_uv, r, uv, t, &h);
+        plane_test<true>(S.planes + 3 * best.idx, S.edges, sc.plane_uv, r, uv, t, &h);
     } else if (best.cls == 1) {
         int gid = f2i(S.cubes[6 * best.idx + 3].z);
         bool uv = f.textures && f2i(sc.mats[3 * gid + 2].y) >= 0;
@@ -547,7 +559,7 @@ DEVI void stage_prims(DevScene& sc, float4* s_prim) {
         const float4* p = s_prim + o; o += words; return p;
     };
     const int n_mats = 3 * (sc.fileset.n_planes + sc.fileset.n_cubes + sc.fileset.n_spheres);
-    const float4* verts = put(sc.fileset.verts, sc.n_verts);
+    const float4* edges = put(sc.fileset.edges, sc.n_verts);
     sc.fileset.planes = put(sc.fileset.planes, 3 * sc.fileset.n_planes);
     sc.fileset.cubes = put(sc.fileset.cubes, 6 * sc.fileset.n_cubes);
     sc.fileset.spheres = put(sc.fileset.spheres, 2 * sc.fileset.n_spheres);
@@ -555,7 +567,7 @@ DEVI void stage_prims(DevScene& sc, float4* s_prim) {
     sc.leafset.cubes = put(sc.leafset.cubes, 6 * sc.leafset.n_cubes);
     sc.leafset.spheres = put(sc.leafset.spheres, 2 * sc.leafset.n_spheres);
     sc.mats = put(sc.mats, n_mats);
-    sc.fileset.verts = verts; sc.leafset.verts = verts;
+    sc.fileset.edges = edges; sc.leafset.edges = edges;
     __syncthreads();
 }
 

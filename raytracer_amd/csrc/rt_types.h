@@ -31,7 +31,8 @@
 // gid = index in scene-file order over planes, then cubes, then spheres; materials are indexed by it.
 struct DevPrimSet {
     const float4* planes;
-    const float4* verts;
+    const float4* verts;           // polygon vertices, projected: (kept, kept, dropped, 0); bounds are made from these
+    const float4* edges;           // per vertex i, the edge from its predecessor j: (Pi.x, Pi.y, Pj.y, slope | NaN), see plane_test
     const float4* cubes;
     const float4* spheres;
     int n_planes, n_cubes, n_spheres;
