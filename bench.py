@@ -162,7 +162,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=3,
+    ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="contexts rendering consecutive frames concurrently on their own streams (1 = one frame at a time)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true",
@@ -201,6 +201,7 @@ def main():
     ls = rdist.broadcast_scene(ls, bool(cfg.bvh), 0, on_dev)
     # Frames in flight: consecutive frames are independent, so P contexts (each with its own work buffers and stream)
     # render them concurrently; a frame's small launches (deep recursion levels) then fill the other frames' gaps.
+    # Four by default: one per hardware queue of the process (more share queues and lose again).
     # Not used for frames of many batches, which keep the GPU busy on their own.  With three or more frames in flight
     # the contexts do not fork their shadow launches onto second streams: the frames already overlap each other, and
     # a process has only four hardware queues for all of its streams.

@@ -832,10 +832,11 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     int* s_stack = (int*)(s_mem + 2 * sc.n_nodes) + threadIdx.x;                      // [depth][thread], only with SUB
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
     __shared__ int s_first[RT_MAX_LEVELS];                              // dense index of each level's first hit
+    __shared__ int s_base[RT_MAX_LEVELS];                               // node index = dense index + s_base[level]
     if (threadIdx.x == 0) {
         int acc = 0;
         for (int lv = 0; lv <= f.max_depth; ++lv) {
-            s_first[lv] = acc;
+            s_first[lv] = acc; s_base[lv] = w.node_off[lv] - acc;
             if (lv < lv_begin || lv > lv_end) continue;                 // this launch covers levels lv_begin..lv_end only
             acc += min(w.ctr[RT_CTR_NODE(lv)], w.node_off[lv + 1] - w.node_off[lv]);
         }
@@ -858,6 +859,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     const int ss_shift = 31 - __clz(SS);
     int* __restrict__ out = (int*)w.shadow;
     unsigned long long n_rays = 0;
+    const float4 light0 = sc.lights[0];                                 // count > 0 implies a light; the usual scene has one
 
     for (unsigned it = 0; it < rounds; ++it) {
         const unsigned i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
@@ -871,9 +873,9 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
             if (L == 1) { dense = (int)grp; l = 0; } else { dense = (int)(grp / (unsigned)L); l = (int)(grp % (unsigned)L); }
             int lv = 0;
             while (lv < f.max_depth && dense >= s_first[lv + 1]) ++lv;
-            node = w.node_off[lv] + (dense - s_first[lv]);
+            node = dense + s_base[lv];                                  // (a per-lane index into the kernel arguments would be a global load)
             float4 a = w.n_a[node], b = w.n_b[node];
-            float4 lt = sc.lights[l];
+            float4 lt = (L == 1) ? light0 : sc.lights[l];
             V3 p = mk(a.x, a.y, a.z);
             Ray sr; sr.time = a.w;
             Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;

@@ -15,8 +15,10 @@ ORDER = ["config1", "config2", "config3", "config3u", "bvh5", "bvh5u", "cube_mb"
 
 
 def run(workload: str, in_flight: int, steps: int, warmup: int) -> dict:
-    cmd = [sys.executable, str(ROOT / "bench.py"), "--workload", workload, "--no-cpu-baseline", "--frames-in-flight", str(in_flight),
-           "--steps", str(steps), "--warmup", str(warmup)]
+    """in_flight = 0: bench.py's default"""
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--workload", workload, "--no-cpu-baseline", "--steps", str(steps), "--warmup", str(warmup)]
+    if in_flight:
+        cmd += ["--frames-in-flight", str(in_flight)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     if out.returncode != 0:
         raise RuntimeError(f"{' '.join(cmd)} failed:\n{out.stderr[-2000:]}")
@@ -35,7 +37,7 @@ def main():
                  "one_frame_at_a_time": {"ms_per_step": one["ms_per_step"], "rays_per_s": one["value"]},
                  "kernel_ms_of_one_profiled_frame": {k: v["ms"] for k, v in one["roofline"]["by_kernel"].items()}}
         if not heavy:
-            many = run(wl, 3, steps, warmup)
+            many = run(wl, 0, steps, warmup)
             entry["frames_in_flight"] = {"n": many["config"]["frames_in_flight"], "ms_per_step": many["ms_per_step"],
                                          "rays_per_s": many["value"], "frame_ms_alone": many["config"]["frame_ms_alone"]}
         res[wl] = entry
