@@ -207,7 +207,7 @@ def main():
     # a process has only four hardware queues for all of its streams.
     P = max(1, args.frames_in_flight) if cfg.samples_per_pixel() <= 64 else 1
     if world > 1:
-        P = min(P, 2)                                 # the gather and the re-ordering need streams (hardware queues) too
+        P = min(P, 3)                                 # the communicator's stream takes the fourth hardware queue
 
     def new_renderer():
         rr = api.Renderer(local, workspace_bytes=16 << 30)
@@ -244,8 +244,10 @@ def main():
     # frame k + 1.  Buffers are reused every other frame behind events; the timed region ends with a device-wide
     # synchronisation, so every frame's image has reached rank 0 inside it.
     pipelined = world > 1 and not staged
-    asm_stream = torch.cuda.Stream(dev) if (pipelined and rank == 0) else None
-    pipes = [rdist.FramePipeline(rr, cfg, rank, world, dev, ss, asm_stream=asm_stream) for rr, ss, _ in ctxs] if pipelined else None
+    # With several pipelines taking turns, rank 0 re-orders each frame on that frame's own render stream (no fifth stream)
+    inline = P >= 2
+    asm_stream = torch.cuda.Stream(dev) if (pipelined and rank == 0 and not inline) else None
+    pipes = [rdist.FramePipeline(rr, cfg, rank, world, dev, ss, asm_stream=asm_stream, assemble_inline=inline) for rr, ss, _ in ctxs] if pipelined else None
     frame_no = [0]
 
     def step():

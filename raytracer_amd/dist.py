@@ -100,9 +100,13 @@ class FramePipeline:
     image on a third stream.  Buffers are reused every other frame behind the gather handle and an event.
     `render_stream` must be the stream the renderer enqueues on (torch.cuda.ExternalStream(renderer.stream_handle()), or
     a torch stream handed to renderer.set_stream beforehand).  `start_gather(block, out_or_None)` returns a handle whose wait() makes the current stream wait for the transfer
-    (gather_blocks_async over RCCL; tests substitute device copies)."""
+    (gather_blocks_async over RCCL; tests substitute device copies).
+    assemble_inline: rank 0 re-orders on `render_stream` itself, behind the gather, instead of on a third stream.  That
+    stalls nothing when several pipelines take turns (the stream's next frame is a few frames away) and saves one of
+    the process's few hardware queues."""
 
-    def __init__(self, renderer, cfg, rank: int, world: int, device, render_stream, start_gather=gather_blocks_async, asm_stream=None):
+    def __init__(self, renderer, cfg, rank: int, world: int, device, render_stream, start_gather=gather_blocks_async, asm_stream=None,
+                 assemble_inline: bool = False):
         self.r, self.cfg, self.rank, self.world = renderer, cfg, rank, world
         self.stream = render_stream
         self.start_gather = start_gather
@@ -111,7 +115,8 @@ class FramePipeline:
         self.gathered = [torch.empty(world * n, dtype=torch.uint8, device=device) if rank == 0 else None for _ in range(2)]
         self.image = torch.empty(renderer.width * renderer.height * 3, dtype=torch.uint8, device=device) if rank == 0 else None
         # several pipelines of one process can share the re-ordering stream (every stream takes one of few hardware queues)
-        self.asm_stream = (asm_stream or torch.cuda.Stream(device)) if rank == 0 else None
+        self.inline = assemble_inline
+        self.asm_stream = (asm_stream or torch.cuda.Stream(device)) if (rank == 0 and not assemble_inline) else None
         self.pending = [None, None]
         self.asm_done = [None, None]
         self.frame = 0
@@ -126,7 +131,10 @@ class FramePipeline:
                 self.stream.wait_event(self.asm_done[b])        # the re-ordering that last read gathered[b]
             self.r.render_device(self.cfg, self.blocks[b].data_ptr())             # on render_stream, the context's stream
             self.pending[b] = self.start_gather(self.blocks[b], self.gathered[b])
-        if self.rank == 0:
+            if self.rank == 0 and self.inline:
+                self.pending[b].wait()                          # stream order also protects gathered[b] and the image
+                self.r.assemble(self.gathered[b].data_ptr(), self.world, self.image.data_ptr())
+        if self.rank == 0 and not self.inline:
             with torch.cuda.stream(self.asm_stream):
                 self.pending[b].wait()
                 self.r.set_stream(self.asm_stream.cuda_stream)

@@ -367,7 +367,8 @@ def test_shadow_overlap_equals_serial_launches():
         assert np.array_equal(img, base), f"overlap, graphs = {key} differs from the serial frame"
 
 
-def test_pipelined_frames_two_shards_in_one_process():
+@pytest.mark.parametrize("inline", [False, True])
+def test_pipelined_frames_two_shards_in_one_process(inline):
     """The multi-rank frame pipeline (render k+1 beside gather k and the re-ordering of k, double-buffered) with two
     shard contexts on one GPU and device copies standing in for the RCCL gather.  Every frame uses another seed, so a
     block or gather buffer that is reused too early shows up as a wrong final image."""
@@ -409,7 +410,8 @@ def test_pipelined_frames_two_shards_in_one_process():
             return h
         return start
 
-    pipes = [rdist.FramePipeline(rs[k], copy.copy(cfg), k, world, dev, torch.cuda.ExternalStream(rs[k].stream_handle(), device=dev), make_gather(k))
+    pipes = [rdist.FramePipeline(rs[k], copy.copy(cfg), k, world, dev, torch.cuda.ExternalStream(rs[k].stream_handle(), device=dev), make_gather(k),
+                                 assemble_inline=inline)
              for k in range(world)]
     frames = 7
     for frame in range(frames):
