@@ -839,7 +839,7 @@ struct StageTimer {
 };
 
 // Enqueue one frame.  out_dev: device buffer in the layout rt_render_device documents.
-static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev, bool want_stats_zero, StageTimer* tm) {
+static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev, bool want_stats_zero, StageTimer* tm, bool count_stats = true) {
     if (!c->have_scene) return c->fail(RT_ERR_STATE, "render before rt_upload_scene");
     if (cfg->bvh && !c->have_bvh) return c->fail(RT_ERR_STATE, "config asks for the BVH but none was uploaded");
     const int AA = cfg->anti_aliasing ? cfg->aa_samples : 1;
@@ -866,7 +866,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     // the retry is exact and, through the file-order set's hierarchy, cheap at any scene size: on unless opted out
     int fb = cfg->fallback; if (fb == 0) fb = 1;
     f.fallback_full = (fb == 1);
-    f.light_radius = cfg->light_radius; f.seed = cfg->seed; f.fast_samples = c->fast_samples ? 1 : 0;
+    f.light_radius = cfg->light_radius; f.seed = cfg->seed; f.fast_samples = c->fast_samples ? 1 : 0; f.count_stats = count_stats ? 1 : 0;
     f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y; f.n_local_tiles = (int)c->local_tiles.size(); f.local_tiles = c->d_local_tiles.p;
 
     const long long n_slots = (long long)c->local_tiles.size() * RT_TILE_PIX;
@@ -1026,7 +1026,7 @@ int rt_render_device(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev, rt_stat
             RT_HIP(c, hipSetDevice(c->device));
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                int rc = enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true, nullptr);
+                int rc = enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true, nullptr, false);
                 hipError_t e = hipStreamEndCapture(c->stream, &graph);
                 if (rc == RT_OK && e == hipSuccess && graph && c->last_batches <= 64 &&
                     hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
@@ -1046,7 +1046,7 @@ int rt_render_device(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev, rt_stat
         }
     }
     StageTimer tm; tm.on = stats != nullptr; tm.pool = &c->event_pool;
-    int rc = enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true, &tm);
+    int rc = enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true, &tm, stats != nullptr);
     if (rc != RT_OK) { double sm[ST_COUNT]; (void)hipStreamSynchronize(c->stream); tm.collect(sm); return rc; }
     if (!stats) return RT_OK;
     RT_HIP(c, hipStreamSynchronize(c->stream));

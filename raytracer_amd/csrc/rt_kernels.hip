@@ -804,6 +804,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
             if (n_reflect) n_refl_ref += (unsigned long long)mult * (unsigned)f.gr_samples;
         }
     }
+    if (!f.count_stats) return;                                        // ray statistics only for frames that ask for them
     if (PRIMARY) block_stat_add(&w.stats[RT_S_PRIMARY], n_primary, s_tmp);
     block_stat_add(&w.stats[RT_S_SHADOW_REF], n_shadow_ref, s_tmp);
     if (spawn) {
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
             atomicAdd(&out[node * L + l], 1);                            // buffer zeroed by the host for this layout
         }
     }
-    block_stat_add(&w.stats[RT_S_SHADOW], n_rays, s_tmp);
+    if (f.count_stats) block_stat_add(&w.stats[RT_S_SHADOW], n_rays, s_tmp);
 }
 
 // raytracer.cpp:173-178: truncate a colour to 0..255 and store it at the pixel of a local slot (row-major image, or
@@ -1037,7 +1038,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, Dev
             }
         }
     }
-    block_stat_add(&w.stats[RT_S_NODES], n_shaded, s_tmp);
+    if (f.count_stats) block_stat_add(&w.stats[RT_S_NODES], n_shaded, s_tmp);
 }
 
 // raytracer.cpp:171-178: average over the samples and truncate to 0..255.
