@@ -880,40 +880,50 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     const bool grouped = !cfg->soft_shadows || (cfg->ss_samples <= 64 && (cfg->ss_samples & (cfg->ss_samples - 1)) == 0);
     double bytes_per = nodes_per * (16.0 * 4 + (f.textures ? 8 : 0) + 4.0 * std::max(L, 1)) + 4.0 + links_per * 4.0 +
                        (k > 0 ? 2.0 * widest * 32.0 : 0.0);
-    long long B = (long long)((double)c->workspace_limit / bytes_per);
+    // (1/64 of the budget covers the rounding of the regions' capacities, see below)
+    long long B = (long long)((double)c->workspace_limit * (63.0 / 64.0) / bytes_per);
     B = std::min(B, n_slots);
     // int32 indexing inside the kernels
     B = std::min(B, (long long)(2.0e9 / std::max(1.0, nodes_per * std::max(1, L) * (cfg->soft_shadows ? cfg->ss_samples : 1))));
     if (B >= RT_TILE_PIX) B -= B % RT_TILE_PIX; else B -= B % 64;
     if (B < 64) return c->fail(RT_ERR_CAPACITY, "workspace of %llu bytes cannot hold one wavefront of samples at depth %d with fan-out %lld",
                                (unsigned long long)c->workspace_limit, D, k);
-    // Per-level regions of the node and link arenas: level d holds at most B * k^d hits / rays.
-    std::vector<long long> node_off((size_t)D + 3, 0), link_off((size_t)D + 3, 0);
+    // Per-level parts of the node and link arenas, each cut into R regions with their own counters.  A region of
+    // level 0 receives the hits of every R-th chunk of 256 primary rays; a region of level d + 1 the rays spawned by
+    // the same region of level d, at most k per hit.  R = RT_REGIONS once a batch has 64 chunks per region (the
+    // rounding of the capacities then costs under 1/64), fewer for small batches, which issue few atomics anyway.
+    std::vector<long long> node_off((size_t)D + 3, 0), link_off((size_t)D + 3, 0), rcap((size_t)D + 3, 0);
+    long long widest_rcap = 0;
+    const long long chunks0 = (B + RT_BLOCK - 1) / RT_BLOCK;
+    int R = 1;
+    while (R < RT_REGIONS && chunks0 >= 64ll * (2 * R)) R *= 2;
     {
         double per = 1.0;
+        const long long rcap0 = ((chunks0 + R - 1) / R) * RT_BLOCK;
         for (int d = 0; d <= D; ++d) {
-            long long cap = (long long)((double)B * per) + 64;
-            node_off[(size_t)d + 1] = node_off[(size_t)d] + cap;
-            if (d >= 1) link_off[(size_t)d + 1] = link_off[(size_t)d] + cap;
+            rcap[(size_t)d] = (long long)((double)rcap0 * per) + (d ? 64 : 0);
+            node_off[(size_t)d + 1] = node_off[(size_t)d] + R * rcap[(size_t)d];
+            if (d >= 1) { link_off[(size_t)d + 1] = link_off[(size_t)d] + R * rcap[(size_t)d]; widest_rcap = std::max(widest_rcap, rcap[(size_t)d]); }
             per *= (double)k;
         }
         link_off[(size_t)D + 2] = link_off[(size_t)D + 1];
     }
     const size_t cap_nodes = (size_t)node_off[(size_t)D + 1];
     const size_t cap_links = (size_t)link_off[(size_t)D + 1] + 64;
-    const size_t cap_rays = k > 0 ? (size_t)((double)B * widest) + 64 : 64;
+    const size_t cap_rays = k > 0 ? (size_t)(R * widest_rcap) + 64 : 64;
+    const size_t cap_pix = (size_t)(R * rcap[0]);                        // n_pix is indexed by the level-0 node
     if (cap_nodes > 0x7fffffffull || cap_links > 0x7fffffffull) return c->fail(RT_ERR_CAPACITY, "batch too large for 32-bit node indices");
 
     hipStream_t s = c->stream;
     RT_HIP(c, hipSetDevice(c->device));
     const bool grow = cap_nodes > c->n_a.n || cap_links > c->link.n || cap_rays > c->q_a[0].n || (size_t)n_slots > c->accum.n ||
-                      (f.textures && cap_nodes > c->n_uv.n) || cap_nodes * (size_t)std::max(L, 1) > c->shadow.n || (size_t)B > c->n_pix.n;
+                      (f.textures && cap_nodes > c->n_uv.n) || cap_nodes * (size_t)std::max(L, 1) > c->shadow.n || cap_pix > c->n_pix.n;
     if (grow) RT_HIP(c, hipStreamSynchronize(s));
     for (int q = 0; q < 2; ++q) { RT_HIP(c, c->q_a[q].resize(cap_rays)); RT_HIP(c, c->q_b[q].resize(cap_rays)); }
     RT_HIP(c, c->n_a.resize(cap_nodes)); RT_HIP(c, c->n_b.resize(cap_nodes)); RT_HIP(c, c->n_c.resize(cap_nodes));
     RT_HIP(c, c->n_col.resize(cap_nodes));
     if (f.textures) RT_HIP(c, c->n_uv.resize(cap_nodes));
-    RT_HIP(c, c->n_pix.resize((size_t)B));
+    RT_HIP(c, c->n_pix.resize(cap_pix));
     RT_HIP(c, c->shadow.resize(cap_nodes * (size_t)std::max(L, 1)));
     RT_HIP(c, c->link.resize(cap_links));
     RT_HIP(c, c->accum.resize((size_t)n_slots));
@@ -925,7 +935,11 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     w.n_a = c->n_a.p; w.n_b = c->n_b.p; w.n_c = c->n_c.p; w.n_uv = c->n_uv.p; w.n_col = c->n_col.p; w.n_pix = c->n_pix.p;
     w.shadow = c->shadow.p; w.link = c->link.p; w.accum = c->accum.p; w.ctr = c->ctr.p; w.stats = c->stats.p;
     w.cap_nodes = (unsigned)cap_nodes;
-    for (int d = 0; d <= D + 2 && d < RT_MAX_LEVELS; ++d) { w.node_off[d] = (int)node_off[(size_t)std::min(d, D + 1)]; w.link_off[d] = (int)link_off[(size_t)d]; }
+    for (int d = 0; d <= D + 2 && d < RT_MAX_LEVELS; ++d) {
+        w.node_off[d] = (int)node_off[(size_t)std::min(d, D + 1)]; w.link_off[d] = (int)link_off[(size_t)d];
+        w.node_rcap[d] = d <= D ? (int)rcap[(size_t)d] : 0; w.link_rcap[d] = (d >= 1 && d <= D) ? (int)rcap[(size_t)d] : 0;
+    }
+    w.regions = R;
 
     const int tile_major = c->world > 1;
     const size_t out_bytes = tile_major ? (size_t)c->max_tiles * RT_TILE_PIX * 3 : (size_t)f.width * (size_t)f.height * 3;

@@ -659,20 +659,40 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
     const int4* s_leaves = SUB ? sc.leaves : (const int4*)(s_mem + 2 * sc.n_nodes);
     int* s_stack = (int*)(s_mem + 2 * sc.n_nodes) + threadIdx.x;                      // [depth][thread], only with SUB
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
-    const int count = PRIMARY ? f.pix_count : min(w.ctr[RT_CTR_LINK(level)], w.link_off[level + 1] - w.link_off[level]);
-    if ((int)(blockIdx.x * blockDim.x) >= count) return;               // whole workgroup idle
+    // The launch's work = chunks of RT_BLOCK rays: consecutive pixel slots for primary rays, consecutive queue slots
+    // of one region otherwise.  Workgroup b takes chunks b, b + gridDim.x, ...
+    __shared__ int s_pre[RT_REGIONS + 1], s_cnt[RT_REGIONS];           // first chunk and ray count of every region
+    if (!PRIMARY) {
+        if (threadIdx.x == 0) {
+            int acc = 0;
+            for (int rg = 0; rg < w.regions; ++rg) {
+                const int n = min(w.ctr[RT_CTR_LINK(level, rg)], w.link_rcap[level]);
+                s_cnt[rg] = n; s_pre[rg] = acc; acc += (n + RT_BLOCK - 1) / RT_BLOCK;
+            }
+            s_pre[w.regions] = acc;
+        }
+        __syncthreads();
+    }
+    const int n_chunks = PRIMARY ? (f.pix_count + RT_BLOCK - 1) / RT_BLOCK : s_pre[w.regions];
+    if ((int)blockIdx.x >= n_chunks) return;                           // whole workgroup idle
     if (f.use_bvh) stage_bvh(sc, s_nodes, (int4*)(s_mem + 2 * sc.n_nodes), !SUB);
     if (LDSP) stage_prims(sc, s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves);
 
     const int link_in = PRIMARY ? 0 : w.link_off[level];
-    const int node_base = w.node_off[level], node_cap = w.node_off[level + 1] - w.node_off[level];
-    const int link_out = w.link_off[level + 1], link_cap = w.link_off[level + 2] - w.link_off[level + 1];
+    const int node_base = w.node_off[level], node_cap = w.node_rcap[level];
+    const int link_out = w.link_off[level + 1], link_cap = w.link_rcap[level + 1];
+    // queue slot of this thread's ray in chunk g, or -1 past the end of the chunk's region (region returned in rg)
+    int seg = 0;
+    auto locate = [&](int g, int& rg) -> int {
+        while (seg < w.regions - 1 && g >= __builtin_amdgcn_readfirstlane(s_pre[seg + 1])) ++seg;
+        rg = seg;
+        const int local = (g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * RT_BLOCK + (int)threadIdx.x;
+        return local < __builtin_amdgcn_readfirstlane(s_cnt[seg]) ? seg * w.link_rcap[level] + local : -1;
+    };
     const float4* __restrict__ qa_in = w.q_a[level & 1];
     const float4* __restrict__ qb_in = w.q_b[level & 1];
     float4* __restrict__ qa_out = w.q_a[(level + 1) & 1];
     float4* __restrict__ qb_out = w.q_b[(level + 1) & 1];
-    const int stride = gridDim.x * blockDim.x;
-    const int rounds = (count + stride - 1) / stride;
     const bool spawn = level < f.max_depth;
     unsigned long long n_primary = 0, n_refl = 0, n_refr = 0, n_shadow_ref = 0, n_refl_ref = 0, n_refr_ref = 0;
     const unsigned long long shadow_per_hit = (unsigned long long)sc.n_lights * (f.soft_shadows ? f.ss_samples : 1);
@@ -683,10 +703,12 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
     // counter, so anything that waits for a load also waits for all older stores: nothing is loaded after a store
     // of the same round, and only the atomic stands between the arithmetic and the stores.
     float4 qa_next = make_float4(0, 0, 0, 0), qb_next = qa_next;
-    if (!PRIMARY) { const int i0 = blockIdx.x * blockDim.x + threadIdx.x; if (i0 < count) { qa_next = qa_in[i0]; qb_next = qb_in[i0]; } }
-    for (int it = 0; it < rounds; ++it) {
-        const int i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        bool active = i < count;
+    int q_next = -1, rg_next = 0;
+    if (!PRIMARY) { q_next = locate((int)blockIdx.x, rg_next); if (q_next >= 0) { qa_next = qa_in[q_next]; qb_next = qb_in[q_next]; } }
+    for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
+        const int i = PRIMARY ? g * RT_BLOCK + (int)threadIdx.x : q_next;        // pixel slot of the batch / queue slot
+        const int rg = PRIMARY ? (g & (w.regions - 1)) : rg_next;                // region this round allocates in
+        bool active = PRIMARY ? i < f.pix_count : i >= 0;
         Ray r; uint32_t path = 0, mult = 1; int slot = 0;
         r.o = mk(0, 0, 0); r.d = mk(0, 0, 1); r.time = 0.0f;
         if (active) {
@@ -697,7 +719,10 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
                 path = (uint32_t)f2i(b.z); mult = (uint32_t)f2i(b.w);
             }
         }
-        if (!PRIMARY) { const int ni = i + stride; if (ni < count) { qa_next = qa_in[ni]; qb_next = qb_in[ni]; } }
+        if (!PRIMARY && g + (int)gridDim.x < n_chunks) {
+            q_next = locate(g + (int)gridDim.x, rg_next);
+            if (q_next >= 0) { qa_next = qa_in[q_next]; qb_next = qb_in[q_next]; }
+        }
         if (PRIMARY && active) ++n_primary;
         Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
         bool hit = active && trace<false, SUB>(sc, f, s_nodes, s_leaves, s_stack, r, !PRIMARY && f.fallback_full, best);
@@ -758,24 +783,25 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
             const int total_children = __shfl(incl, 63, 64), total_hits = __popcll(hm);
             unsigned long long pair = 0;
             if (lane == 0 && (total_hits | total_children))
-                pair = atomicAdd((unsigned long long*)&w.ctr[RT_CTR_NODE(level)],
+                pair = atomicAdd((unsigned long long*)&w.ctr[RT_CTR_NODE(level, rg)],
                                  ((unsigned long long)(unsigned)total_children << 32) | (unsigned long long)(unsigned)total_hits);
             const int base_node = __shfl((int)(unsigned)(pair & 0xffffffffull), 0, 64), base_link = __shfl((int)(unsigned)(pair >> 32), 0, 64);
             if (hit) node = base_node + __popcll(hm & ((1ull << lane) - 1ull));
             qslot = base_link + incl - n_children;
         }
         if (hit && node >= node_cap) { w.stats[RT_S_ERR] = 1; hit = false; }
-        node = hit ? node_base + node : -1;
+        node = hit ? node_base + rg * node_cap + node : -1;
         if (!PRIMARY && active) w.link[link_in + i] = node;
         if (hit) {
             w.n_a[node] = make_float4(h.p.x, h.p.y, h.p.z, r.time);
             w.n_b[node] = make_float4(h.n.x, h.n.y, h.n.z, i2f(h.gid));
             if (f.textures) w.n_uv[node] = make_float2(h.u, h.v);
             if (PRIMARY) w.n_pix[node] = slot;
-            const int first_link = link_out + qslot;
             if (n_children > 0 && qslot + n_children > link_cap) {
                 w.stats[RT_S_ERR] = 1; n_children = 0; n_reflect = 0; refract = false;
             }
+            qslot += rg * link_cap;                                      // the region's part of the next level's queue
+            const int first_link = link_out + qslot;
             w.n_c[node] = make_float4(i2f(n_children ? first_link : -1), weight, i2f((int)path),
                                       i2f(n_reflect | (refract ? (1 << 30) : 0)));
             const float EPS = 1e-4f;
@@ -832,39 +858,45 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     const int4* s_leaves = SUB ? sc.leaves : (const int4*)(s_mem + 2 * sc.n_nodes);
     int* s_stack = (int*)(s_mem + 2 * sc.n_nodes) + threadIdx.x;                      // [depth][thread], only with SUB
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
-    __shared__ int s_first[RT_MAX_LEVELS];                              // dense index of each level's first hit
-    __shared__ int s_base[RT_MAX_LEVELS];                               // node index = dense index + s_base[level]
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int lv = 0; lv <= f.max_depth; ++lv) {
-            s_first[lv] = acc; s_base[lv] = w.node_off[lv] - acc;
-            if (lv < lv_begin || lv > lv_end) continue;                 // this launch covers levels lv_begin..lv_end only
-            acc += min(w.ctr[RT_CTR_NODE(lv)], w.node_off[lv + 1] - w.node_off[lv]);
-        }
-        s_first[f.max_depth + 1] = acc;
-    }
-    __syncthreads();
-    const int n_nodes = s_first[f.max_depth + 1];
+    // The launch's work = chunks of RT_BLOCK shadow rays inside segments; a segment = the hits of one region of one of
+    // the levels lv_begin..lv_end, (hit, light, sample) in that order.  Workgroup b takes chunks b, b + gridDim.x, ...
+    constexpr int MAX_SEG = RT_MAX_LEVELS * RT_REGIONS;
+    __shared__ int s_pre[MAX_SEG + 1];                                  // first chunk of every segment
+    __shared__ unsigned s_items[MAX_SEG];                               // shadow rays of the segment
+    __shared__ int s_nbase[MAX_SEG];                                    // node index of the segment's first hit
     const int L = sc.n_lights;
     constexpr bool FAST = MODE == 2;
     const int SS = MODE ? f.ss_samples : 1;
-    const unsigned per = (unsigned)(L * SS);
-    const unsigned count = (unsigned)n_nodes * per;                      // the host keeps hits x lights x samples below 2^31
-    if (blockIdx.x * blockDim.x >= count) return;
+    const unsigned per = (unsigned)(L * SS);                            // the host keeps hits x lights x samples below 2^31
+    const int n_seg = (lv_end - lv_begin + 1) * w.regions;
+    for (int sg = threadIdx.x; sg < n_seg; sg += blockDim.x) {
+        const int lv = lv_begin + sg / w.regions, rg = sg % w.regions;
+        s_items[sg] = (unsigned)min(w.ctr[RT_CTR_NODE(lv, rg)], w.node_rcap[lv]) * per;
+        s_nbase[sg] = w.node_off[lv] + rg * w.node_rcap[lv];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int sg = 0; sg < n_seg; ++sg) { s_pre[sg] = acc; acc += (int)((s_items[sg] + RT_BLOCK - 1) / RT_BLOCK); }
+        s_pre[n_seg] = acc;
+    }
+    __syncthreads();
+    const int n_chunks = s_pre[n_seg];
+    if ((int)blockIdx.x >= n_chunks) return;
     if (f.use_bvh) stage_bvh(sc, s_nodes, (int4*)(s_mem + 2 * sc.n_nodes), !SUB);
     if (LDSP) stage_prims(sc, s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves);
 
-    const unsigned stride = gridDim.x * blockDim.x;
-    const unsigned rounds = (count + stride - 1) / stride;
     const bool grouped = (SS <= 64) && ((SS & (SS - 1)) == 0);           // a (hit, light) group sits inside one wavefront
     const int ss_shift = 31 - __clz(SS);
     int* __restrict__ out = (int*)w.shadow;
     unsigned long long n_rays = 0;
     const float4 light0 = sc.lights[0];                                 // count > 0 implies a light; the usual scene has one
 
-    for (unsigned it = 0; it < rounds; ++it) {
-        const unsigned i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        const bool active = i < count;
+    int seg = 0;
+    for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
+        while (seg < n_seg - 1 && g >= __builtin_amdgcn_readfirstlane(s_pre[seg + 1])) ++seg;
+        const unsigned i = (unsigned)(g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * RT_BLOCK + threadIdx.x;   // ray of the segment
+        const bool active = i < (unsigned)__builtin_amdgcn_readfirstlane((int)s_items[seg]);
         bool unblocked = false;
         int node = 0, l = 0, j = 0;
         if (active) {
@@ -872,9 +904,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
             if (grouped) { grp = i >> ss_shift; j = (int)(i & (unsigned)(SS - 1)); } else { grp = i / (unsigned)SS; j = (int)(i % (unsigned)SS); }
             int dense;
             if (L == 1) { dense = (int)grp; l = 0; } else { dense = (int)(grp / (unsigned)L); l = (int)(grp % (unsigned)L); }
-            int lv = 0;
-            while (lv < f.max_depth && dense >= s_first[lv + 1]) ++lv;
-            node = dense + s_base[lv];                                  // (a per-lane index into the kernel arguments would be a global load)
+            node = __builtin_amdgcn_readfirstlane(s_nbase[seg]) + dense;
             float4 a = w.n_a[node], b = w.n_b[node];
             float4 lt = (L == 1) ? light0 : sc.lights[l];
             V3 p = mk(a.x, a.y, a.z);
@@ -941,16 +971,29 @@ DEVI void store_pixel(const DevFrame& f, unsigned char* __restrict__ out, int ti
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, DevWork w, int level) {
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
-    const int begin = w.node_off[level];
-    const int count = min(w.ctr[RT_CTR_NODE(level)], w.node_off[level + 1] - w.node_off[level]);
-    if ((int)(blockIdx.x * blockDim.x) >= count) return;
-    const int stride = gridDim.x * blockDim.x;
+    // chunks of RT_BLOCK hits inside the level's regions, as in k_extend
+    __shared__ int s_pre[RT_REGIONS + 1], s_cnt[RT_REGIONS];
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int rg = 0; rg < w.regions; ++rg) {
+            const int n = min(w.ctr[RT_CTR_NODE(level, rg)], w.node_rcap[level]);
+            s_cnt[rg] = n; s_pre[rg] = acc; acc += (n + RT_BLOCK - 1) / RT_BLOCK;
+        }
+        s_pre[w.regions] = acc;
+    }
+    __syncthreads();
+    const int n_chunks = s_pre[w.regions];
+    if ((int)blockIdx.x >= n_chunks) return;
     const int L = sc.n_lights;
     const int* __restrict__ sh = (const int*)w.shadow;
     const V3 cam = mk(f.cam_loc[0], f.cam_loc[1], f.cam_loc[2]);
     unsigned long long n_shaded = 0;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
-        const int node = begin + k;
+    int seg = 0;
+    for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
+        while (seg < w.regions - 1 && g >= __builtin_amdgcn_readfirstlane(s_pre[seg + 1])) ++seg;
+        const int k = (g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * RT_BLOCK + (int)threadIdx.x;
+        if (k >= __builtin_amdgcn_readfirstlane(s_cnt[seg])) continue;
+        const int node = w.node_off[level] + seg * w.node_rcap[level] + k;
         ++n_shaded;
         float4 a = w.n_a[node], b = w.n_b[node], c = w.n_c[node];
         const int gid = f2i(b.w);
@@ -1085,7 +1128,8 @@ __global__ void k_begin_frame(uint4* __restrict__ zero, size_t n_words, int tail
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) zero[i] = make_uint4(0u, 0u, 0u, 0u);
     if (blockIdx.x == 0) {
         if ((int)threadIdx.x < tail_bytes) ((unsigned char*)(zero + n_words))[threadIdx.x] = 0;      // < 16 bytes past the last word
-        for (int i = threadIdx.x; i < RT_C_TOTAL; i += blockDim.x) ctr[i] = 0;
+        for (int i = threadIdx.x; i < RT_REGIONS * 2 * RT_MAX_LEVELS; i += blockDim.x)          // the words in use
+            ctr[(i / (2 * RT_MAX_LEVELS)) * RT_CTR_REGION_INTS + i % (2 * RT_MAX_LEVELS)] = 0;
         if (stats) for (int i = threadIdx.x; i < RT_S_TOTAL; i += blockDim.x) stats[i] = 0ull;
     }
 }

@@ -94,9 +94,13 @@ struct DevFrame {
 //   n_a = (hit point xyz, hit time)           n_b = (geometric normal xyz, bits gid)
 //   n_c = (bits first_link | -1, refraction weight, bits path id, bits n_reflection_children | has_refraction << 30)
 //   n_uv = (u, v) when texture mapping is on   n_col = resolved colour (r, g, b, 0)
-//   n_pix (level 0 only) = local pixel slot.  Node index = node_off[level] + order of allocation inside the level.
+//   n_pix (level 0 only) = local pixel slot.
+// Every level's part of the node arena and of the ray queue is cut into `regions` (<= RT_REGIONS) regions of equal capacity, each
+// filled from its start through its own counter (see ctr below):
+//   node index = node_off[level] + region * node_rcap[level] + order of allocation inside the region
+//   queue slot = region * link_rcap[level] + order of allocation inside the region
 // Secondary-ray queue entry: q_a = (origin xyz, dir.x)  q_b = (dir.y, dir.z, bits path id, bits multiplicity)
-// link[link_off[level] + k] = node index hit by the k-th ray traced at `level`, or -1; queue slot of that ray = k
+// link[link_off[level] + queue slot] = node index hit by that ray of `level`, or -1
 struct DevWork {
     float4* q_a[2]; float4* q_b[2];
     float4* n_a; float4* n_b; float4* n_c; float2* n_uv; float4* n_col; int* n_pix;
@@ -108,16 +112,26 @@ struct DevWork {
     unsigned cap_nodes;            // total node capacity = node_off[max_depth + 1]
     int node_off[RT_MAX_LEVELS];   // [level] first node of the level's region; [max_depth + 1] = end
     int link_off[RT_MAX_LEVELS];   // [level] first link of the rays traced at `level` (level >= 1); [max_depth + 1] = end
+    int node_rcap[RT_MAX_LEVELS];  // [level] nodes one region of the level can hold
+    int link_rcap[RT_MAX_LEVELS];  // [level] rays one region of the level's queue can hold (level >= 1)
+    int regions;                   // regions in use: 1, 2, 4 or RT_REGIONS (small batches do not need the spread)
 };
 
-// ctr[] slots: per-level allocation counters, zeroed at the start of every batch.  Each recursion level owns a
-// fixed region of the node and link arenas (offsets in DevWork, sized on the host for the worst-case fan-out), so
+// ctr[] slots: allocation counters per (level, region), zeroed at the start of every batch.  Each recursion level owns
+// a fixed part of the node and link arenas (offsets in DevWork, sized on the host for the worst-case fan-out), so
 // no kernel ever needs another level's running count and there is no bookkeeping between launches.
 // The hits recorded at `level` and the secondary rays they spawn (to be traced at level + 1) sit in the two halves
 // of one aligned 64-bit word, so a wavefront allocates both with a single atomic.
-#define RT_CTR_NODE(level) (2 * (level))          // hits recorded at `level`
-#define RT_CTR_LINK(level) (2 * (level) - 1)      // secondary rays to trace at `level` (level >= 1)
-enum { RT_C_TOTAL = 2 * RT_MAX_LEVELS };
+// Why regions: returning atomics on one word - or on words a few hundred bytes apart, which one memory channel
+// serves - complete at a fixed rate of roughly a hundred per microsecond, whatever the number of wavefronts; with one
+// counter per level that rate, not the tracing, set the duration of the extend kernels.  A workgroup-round allocates
+// in the region of its 256-ray chunk (chunk index mod RT_REGIONS for primary rays, the region the rays were queued
+// in otherwise), and the regions' counters lie RT_CTR_REGION_INTS * 4 bytes apart.
+#define RT_REGIONS 8
+#define RT_CTR_REGION_INTS 4096
+#define RT_CTR_NODE(level, region) ((region) * RT_CTR_REGION_INTS + 2 * (level))          // hits recorded at `level`
+#define RT_CTR_LINK(level, region) ((region) * RT_CTR_REGION_INTS + 2 * (level) - 1)      // rays queued for `level` (>= 1)
+enum { RT_C_TOTAL = RT_REGIONS * RT_CTR_REGION_INTS };
 // stats[] slots
 // *_REF = what the reference would trace: without glossy perturbation it re-traces gr_samples identical reflection
 // rays per hit, and with them their whole subtrees; every ray carries that multiplicity.
