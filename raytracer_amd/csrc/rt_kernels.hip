@@ -664,16 +664,19 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
     __shared__ int s_pre[RT_REGIONS + 1], s_cnt[RT_REGIONS];           // first chunk and ray count of every region
     if (!PRIMARY) {
         if (threadIdx.x == 0) {
-            int acc = 0;
-            for (int rg = 0; rg < w.regions; ++rg) {
-                const int n = min(w.ctr[RT_CTR_LINK(level, rg)], w.link_rcap[level]);
-                s_cnt[rg] = n; s_pre[rg] = acc; acc += (n + RT_BLOCK - 1) / RT_BLOCK;
+            int acc = 0, n[RT_REGIONS];
+#pragma unroll
+            for (int rg = 0; rg < RT_REGIONS; ++rg) n[rg] = w.ctr[RT_CTR_LINK(level, rg)];      // unused regions' counters stay 0
+#pragma unroll
+            for (int rg = 0; rg < RT_REGIONS; ++rg) {
+                const int m = min(n[rg], w.link_rcap[level]);
+                s_cnt[rg] = m; s_pre[rg] = acc; acc += (m + RT_BLOCK - 1) / RT_BLOCK;
             }
-            s_pre[w.regions] = acc;
+            s_pre[RT_REGIONS] = acc;
         }
         __syncthreads();
     }
-    const int n_chunks = PRIMARY ? (f.pix_count + RT_BLOCK - 1) / RT_BLOCK : s_pre[w.regions];
+    const int n_chunks = PRIMARY ? (f.pix_count + RT_BLOCK - 1) / RT_BLOCK : s_pre[RT_REGIONS];
     if ((int)blockIdx.x >= n_chunks) return;                           // whole workgroup idle
     if (f.use_bvh) stage_bvh(sc, s_nodes, (int4*)(s_mem + 2 * sc.n_nodes), !SUB);
     if (LDSP) stage_prims(sc, s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves);
@@ -974,15 +977,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, Dev
     // chunks of RT_BLOCK hits inside the level's regions, as in k_extend
     __shared__ int s_pre[RT_REGIONS + 1], s_cnt[RT_REGIONS];
     if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int rg = 0; rg < w.regions; ++rg) {
-            const int n = min(w.ctr[RT_CTR_NODE(level, rg)], w.node_rcap[level]);
-            s_cnt[rg] = n; s_pre[rg] = acc; acc += (n + RT_BLOCK - 1) / RT_BLOCK;
+        int acc = 0, n[RT_REGIONS];
+#pragma unroll
+        for (int rg = 0; rg < RT_REGIONS; ++rg) n[rg] = w.ctr[RT_CTR_NODE(level, rg)];          // unused regions' counters stay 0
+#pragma unroll
+        for (int rg = 0; rg < RT_REGIONS; ++rg) {
+            const int m = min(n[rg], w.node_rcap[level]);
+            s_cnt[rg] = m; s_pre[rg] = acc; acc += (m + RT_BLOCK - 1) / RT_BLOCK;
         }
-        s_pre[w.regions] = acc;
+        s_pre[RT_REGIONS] = acc;
     }
     __syncthreads();
-    const int n_chunks = s_pre[w.regions];
+    const int n_chunks = s_pre[RT_REGIONS];
     if ((int)blockIdx.x >= n_chunks) return;
     const int L = sc.n_lights;
     const int* __restrict__ sh = (const int*)w.shadow;
