@@ -53,7 +53,12 @@ for k, c in traffic.items():
     if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
         rd = 2.0 * 1024.0 * c.get("FETCH_SIZE", 0.0); wr = 1024.0 * c.get("WRITE_SIZE", 0.0)
         out[k] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
-json.dump(out, open(f"{root}/traffic.json", "w"), indent=1)
+# the form bench.py reads as profiles/traffic_latest.json (workload: argv[2], default config2)
+wrapped = {"workload": sys.argv[2] if len(sys.argv) > 2 else "config2",
+           "source": "tools/profile.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled for gfx950, "
+                     "both x1024; one frame at a time, library options overlap=0,graphs=0)",
+           "kernels": out}
+json.dump(wrapped, open(f"{root}/traffic.json", "w"), indent=1)
 print("\n== HBM bytes per launch (FETCH_SIZE x2 x1024 + WRITE_SIZE x1024) ==")
 for k, v in out.items():
     print(f"{k:24s} read {v['read_bytes_per_launch']/1e6:10.3f} MB  write {v['write_bytes_per_launch']/1e6:10.3f} MB")
