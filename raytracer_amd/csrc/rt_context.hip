@@ -192,7 +192,9 @@ struct rt_ctx {
     std::vector<float4> h_sub_nodes_file; std::vector<int> h_sub_entries_file;
     int file_sub_root = -1;
     int sub_min_group = RT_SUB_MIN_GROUP;    // groups above this size get a second-level hierarchy (rt_set_option)
-    int max_grid = 2048;                     // 256 CUs x 8 workgroups: enough to fill the chip
+    // workgroups per launch (more work than that is taken in rounds): primary extend, secondary extend, shadow, shade
+    // 0 = chosen per launch (see enqueue_frame)
+    int grid_primary = 0, grid_secondary = 0, grid_shadow = 0, grid_shade = 0;
     bool fast_samples = true;                // soft-shadow sample rays: hardware reciprocals instead of IEEE division
     int lds_prims = 1;                       // tiny scenes: primitive records in LDS; 1 = shadow kernel only, 2 = extend too
     int device_build = 1;                    // hierarchies and leaf-order records are made on the GPU (rt_set_option)
@@ -329,8 +331,15 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "device_build") == 0) { c->device_build = value != 0; return RT_OK; }
     if (std::strcmp(name, "graphs") == 0) { c->use_graphs = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "max_grid") == 0) {
-        if (value < 1 || value > (1 << 20)) return c->fail(RT_ERR_ARG, "max_grid must be 1..%d", 1 << 20);
-        c->max_grid = (int)value; c->drop_graphs(); return RT_OK;
+        if (value < 0 || value > (1 << 20)) return c->fail(RT_ERR_ARG, "max_grid must be 0..%d", 1 << 20);
+        c->grid_primary = c->grid_secondary = c->grid_shadow = c->grid_shade = (int)value; c->drop_graphs(); return RT_OK;
+    }
+    if (std::strncmp(name, "grid_", 5) == 0) {
+        int* which = std::strcmp(name, "grid_primary") == 0 ? &c->grid_primary : std::strcmp(name, "grid_secondary") == 0 ? &c->grid_secondary :
+                     std::strcmp(name, "grid_shadow") == 0 ? &c->grid_shadow : std::strcmp(name, "grid_shade") == 0 ? &c->grid_shade : nullptr;
+        if (!which) return c->fail(RT_ERR_ARG, "unknown option %s", name);
+        if (value < 0 || value > (1 << 20)) return c->fail(RT_ERR_ARG, "%s must be 0..%d", name, 1 << 20);
+        *which = (int)value; c->drop_graphs(); return RT_OK;
     }
     if (std::strcmp(name, "fast_samples") == 0) { c->fast_samples = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "overlap") == 0) { c->overlap = value != 0; c->drop_graphs(); return RT_OK; }
@@ -950,7 +959,6 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     if (direct) rt_launch_begin_frame(s, w, out_dev, out_bytes, want_stats_zero);
     else rt_launch_begin_frame(s, w, c->accum.p, (size_t)n_slots * sizeof(float4), want_stats_zero);
 
-    const int max_grid = c->max_grid;        // workgroups per launch; grid-stride beyond that
     unsigned long long batches = 0;
     StageTimer local_tm; if (!tm) { tm = &local_tm; tm->pool = &c->event_pool; }
     tm->s = s;
@@ -962,29 +970,45 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     for (long long begin = 0; begin < n_slots; begin += B) {
         const int count = (int)std::min<long long>(B, n_slots - begin);
         f.pix_begin = (int)begin; f.pix_count = count;
-        const int grid0 = std::max(1, std::min(max_grid, (count + RT_BLOCK - 1) / RT_BLOCK));
+        const int chunks0_batch = (count + RT_BLOCK - 1) / RT_BLOCK;
+        // Workgroups per launch; more work than that is taken in rounds.  1024 is what is resident at once (256 CUs x 4
+        // workgroups of 4 wavefronts): for kernels whose workgroups are cheap to start and whose rounds cost about the
+        // same, a second generation of workgroups only adds start-up cost and an uneven tail.  Launches with very many
+        // chunks of unequal cost (walks of second-level hierarchies, tens of thousands of chunks of glossy rays) do
+        // better when the dispatcher hands out a second generation as workgroups finish.  Measured per kernel on
+        // scene.json, bvh_vs_unaccel_5, cube_mb and 10^6 primitives; rt_set_option("grid_*") overrides.
+        const bool sub = c->scene.sub_nodes != nullptr;
+        const int g_primary = c->grid_primary ? c->grid_primary : (sub ? 2048 : 1024);
+        const int g_shade = c->grid_shade ? c->grid_shade : 1024;
+        const int g_shadow = c->grid_shadow ? c->grid_shadow : ((!sub && cfg->soft_shadows && c->fast_samples) ? 1536 : 2048);
+        auto g_secondary = [&](int level) {
+            if (c->grid_secondary) return c->grid_secondary;
+            const long long worst_chunks = (long long)w.regions * w.link_rcap[level] / RT_BLOCK;
+            return (sub || worst_chunks > 16384) ? 2048 : 1024;
+        };
+        const int grid0 = std::max(1, std::min(g_primary, chunks0_batch));
         for (int smp = 0; smp < S; ++smp) {
             f.sample = smp;
             if (batches > 0) RT_HIP(c, hipMemsetAsync(c->ctr.p, 0, RT_C_TOTAL * sizeof(int), s));   // counters of the batch
             if (!grouped) RT_HIP(c, hipMemsetAsync(c->shadow.p, 0, cap_nodes * (size_t)std::max(L, 1) * sizeof(float), s));
             for (int level = 0; level <= D; ++level) {
                 tm->begin(level == 0 ? ST_EXTEND_PRIMARY : ST_EXTEND_SECONDARY);
-                rt_launch_extend(s, c->scene, f, w, level, level == 0 ? grid0 : max_grid);
+                rt_launch_extend(s, c->scene, f, w, level, level == 0 ? grid0 : g_secondary(level));
                 tm->end();
                 if (level == 0 && split) {
                     // the primary hits are final: their shadow rays start now, beside the deeper levels' tracing
                     hipStream_t ss = overlap ? c->aux_stream : s;
                     if (overlap) { RT_HIP(c, hipEventRecord(c->ev_fork, s)); RT_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0)); }
-                    tm->begin(ST_SHADOW); rt_launch_shadow(ss, c->scene, f, w, 0, 0, max_grid); tm->end();
+                    tm->begin(ST_SHADOW); rt_launch_shadow(ss, c->scene, f, w, 0, 0, g_shadow); tm->end();
                     if (overlap) RT_HIP(c, hipEventRecord(c->ev_join, c->aux_stream));
                 }
             }
-            if (L > 0) { tm->begin(ST_SHADOW); rt_launch_shadow(s, c->scene, f, w, split ? 1 : 0, D, max_grid); tm->end(); }
+            if (L > 0) { tm->begin(ST_SHADOW); rt_launch_shadow(s, c->scene, f, w, split ? 1 : 0, D, g_shadow); tm->end(); }
             for (int level = D; level >= 0; --level) {
                 // only the primary hits' shading needs the forked launch; the deeper levels resolve beside it
                 if (overlap && level == 0) RT_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
                 tm->begin(ST_SHADE);
-                rt_launch_shade(s, c->scene, f, w, level, level == 0 ? grid0 : max_grid);
+                rt_launch_shade(s, c->scene, f, w, level, level == 0 ? std::max(1, std::min(g_shade, chunks0_batch)) : g_shade);
                 tm->end();
             }
             ++batches;
