@@ -978,7 +978,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         // better when the dispatcher hands out a second generation as workgroups finish.  Measured per kernel on
         // scene.json, bvh_vs_unaccel_5, cube_mb and 10^6 primitives; rt_set_option("grid_*") overrides.
         const bool sub = c->scene.sub_nodes != nullptr;
-        const int g_primary = c->grid_primary ? c->grid_primary : (sub ? 2048 : 1024);
+        const int g_primary = c->grid_primary ? c->grid_primary : ((!sub && c->scene.lds_prims) ? 1024 : 2048);   // 1024: a handful of primitives
         const int g_shade = c->grid_shade ? c->grid_shade : 1024;
         const int g_shadow = c->grid_shadow ? c->grid_shadow : ((!sub && cfg->soft_shadows && c->fast_samples) ? 1536 : 2048);
         auto g_secondary = [&](int level) {
