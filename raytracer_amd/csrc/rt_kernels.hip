@@ -649,7 +649,8 @@ DEVI bool generate_primary(const DevFrame& f, int i, Ray& r, uint32_t& path, int
 // extend: trace one ray per lane to the hit the reference would report, append a hit-tree node, and spawn the
 // reflection / refraction rays of the next level (raytracer.cpp:144-164 for primaries, :373-498 for the spawn).
 // ---------------------------------------------------------------------------------------------------------
-template <bool PRIMARY, bool SUB, bool LDSP>
+// STATS: the kernel keeps the six per-thread ray counts (twelve registers it otherwise has to spill)
+template <bool PRIMARY, bool SUB, bool LDSP, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAVES) void k_extend(DevScene sc_arg, DevFrame f, DevWork w, int level) {
     extern __shared__ float4 s_mem[];
     DevScene sc = sc_arg;
@@ -726,14 +727,14 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
             q_next = locate(g + (int)gridDim.x, rg_next);
             if (q_next >= 0) { qa_next = qa_in[q_next]; qb_next = qb_in[q_next]; }
         }
-        if (PRIMARY && active) ++n_primary;
+        if (STATS && PRIMARY && active) ++n_primary;
         Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
         bool hit = active && trace<false, SUB>(sc, f, s_nodes, s_leaves, s_stack, r, !PRIMARY && f.fallback_full, best);
 
         int n_children = 0, n_reflect = 0; bool refract = false;
         HitOut h; V3 N = mk(0, 0, 1), rd = mk(0, 0, 1), fd = mk(0, 0, 1); float weight = 0.0f, gloss_angle = 0.0f; bool glossy = false;
         if (hit) {
-            n_shadow_ref += shadow_per_hit * mult;
+            if (STATS) n_shadow_ref += shadow_per_hit * mult;
             full_hit(sc, f, r, best, h);
             if (spawn) {
                 float4 m0 = sc.mats[3 * h.gid], m1 = sc.mats[3 * h.gid + 1], m2 = sc.mats[3 * h.gid + 2];
@@ -827,13 +828,15 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
                 uint32_t cpath = mix32(path * 0x9E3779B1u + 0x7FFFFFFFu);
                 qa_out[qslot + n_reflect] = make_float4(org.x, org.y, org.z, fd.x);
                 qb_out[qslot + n_reflect] = make_float4(fd.y, fd.z, i2f((int)cpath), i2f((int)mult));
-                ++n_refr; n_refr_ref += mult;
+                if (STATS) { ++n_refr; n_refr_ref += mult; }
             }
-            n_refl += (unsigned)n_reflect;
-            if (n_reflect) n_refl_ref += (unsigned long long)mult * (unsigned)f.gr_samples;
+            if (STATS) {
+                n_refl += (unsigned)n_reflect;
+                if (n_reflect) n_refl_ref += (unsigned long long)mult * (unsigned)f.gr_samples;
+            }
         }
     }
-    if (!f.count_stats) return;                                        // ray statistics only for frames that ask for them
+    if (!STATS) return;                                                // ray statistics only for frames that ask for them
     if (PRIMARY) block_stat_add(&w.stats[RT_S_PRIMARY], n_primary, s_tmp);
     block_stat_add(&w.stats[RT_S_SHADOW_REF], n_shadow_ref, s_tmp);
     if (spawn) {
@@ -1158,15 +1161,19 @@ void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, cons
     size_t lds = bvh_lds_bytes(sc, f);
     const bool sub = sc.sub_nodes != nullptr;
     const bool ldsp = !sub && sc.lds_prims > 1;
+#define RT_EXTEND_LAUNCH(PRIMARY, SUB, LDSP) \
+    do { if (f.count_stats) hipLaunchKernelGGL((k_extend<PRIMARY, SUB, LDSP, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level); \
+         else hipLaunchKernelGGL((k_extend<PRIMARY, SUB, LDSP, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level); } while (0)
     if (level == 0) {
-        if (sub) hipLaunchKernelGGL((k_extend<true, true, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
-        else if (ldsp) hipLaunchKernelGGL((k_extend<true, false, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
-        else hipLaunchKernelGGL((k_extend<true, false, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+        if (sub) RT_EXTEND_LAUNCH(true, true, false);
+        else if (ldsp) RT_EXTEND_LAUNCH(true, false, true);
+        else RT_EXTEND_LAUNCH(true, false, false);
     } else {
-        if (sub) hipLaunchKernelGGL((k_extend<false, true, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
-        else if (ldsp) hipLaunchKernelGGL((k_extend<false, false, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
-        else hipLaunchKernelGGL((k_extend<false, false, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level);
+        if (sub) RT_EXTEND_LAUNCH(false, true, false);
+        else if (ldsp) RT_EXTEND_LAUNCH(false, false, true);
+        else RT_EXTEND_LAUNCH(false, false, false);
     }
+#undef RT_EXTEND_LAUNCH
 }
 
 void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid) {
