@@ -273,9 +273,15 @@ def main():
 
     # Ray counts (identical every frame: the generator is counter based) and per-kernel device times.  The profiled
     # frame is enqueued behind four ordinary ones so that the GPU, not the host, paces it.
+    st = r.render_device(cfg, block.data_ptr(), want_stats=True)     # ray counts (the counting kernel variants)
     for _ in range(4):
         r.render_device(cfg, block.data_ptr())
-    st = r.render_device(cfg, block.data_ptr(), want_stats=True)
+    r.set_option("count_rays", 0)                                    # stage times with the kernels the timed frames run
+    tm = r.render_device(cfg, block.data_ptr(), want_stats=True)
+    r.set_option("count_rays", 1)
+    for name in ("ms_extend_primary", "ms_extend_secondary", "ms_shadow", "ms_shade", "ms_other", "ms_total",
+                 "launches_extend_primary", "launches_extend_secondary", "launches_shadow", "launches_shade"):
+        setattr(st, name, getattr(tm, name))
     rays_local = torch.tensor([st.primary_rays, st.shadow_rays, st.reflection_rays, st.refraction_rays,
                                st.shadow_rays_ref + st.reflection_rays_ref + st.refraction_rays_ref, st.nodes_shaded],
                               dtype=torch.float64, device=dev)

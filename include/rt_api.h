@@ -194,6 +194,8 @@ void* rt_get_stream(rt_ctx* ctx);
  * output pointer and stream, and replays it afterwards; default 1.  "overlap" = 0/1: whether frames rendered
  * without statistics trace the shadow rays of the primary hits on a second, internal stream while the render
  * stream traces the deeper recursion levels (joined before shading; the caller sees one stream); default 1.
+ * "count_rays" = 0/1: whether rt_render_device with a statistics pointer counts rays (default 1) or only times the
+ * stages, with the kernels plain frames use (the ray counts then read 0).
  * "max_grid" (all kernels) or "grid_primary" / "grid_secondary" / "grid_shadow" / "grid_shade" = workgroups per launch,
  * 0 = chosen per launch (default).  The one switch that does move rendered values, and only those
  * of soft-shadow renders, within their sampling noise: "fast_samples" = 0/1, whether the randomly drawn soft-shadow

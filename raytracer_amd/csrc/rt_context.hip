@@ -193,6 +193,7 @@ struct rt_ctx {
     int file_sub_root = -1;
     int sub_min_group = RT_SUB_MIN_GROUP;    // groups above this size get a second-level hierarchy (rt_set_option)
     // workgroups per launch (more work than that is taken in rounds): primary extend, secondary extend, shadow, shade
+    bool count_rays = true;                  // frames with statistics count rays (off: stage times only, at the speed of plain frames)
     // 0 = chosen per launch (see enqueue_frame)
     int grid_primary = 0, grid_secondary = 0, grid_shadow = 0, grid_shade = 0;
     bool fast_samples = true;                // soft-shadow sample rays: hardware reciprocals instead of IEEE division
@@ -341,6 +342,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > (1 << 20)) return c->fail(RT_ERR_ARG, "%s must be 0..%d", name, 1 << 20);
         *which = (int)value; c->drop_graphs(); return RT_OK;
     }
+    if (std::strcmp(name, "count_rays") == 0) { c->count_rays = value != 0; return RT_OK; }
     if (std::strcmp(name, "fast_samples") == 0) { c->fast_samples = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "overlap") == 0) { c->overlap = value != 0; c->drop_graphs(); return RT_OK; }
     return c->fail(RT_ERR_ARG, "unknown option %s", name);
@@ -1084,7 +1086,7 @@ int rt_render_device(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev, rt_stat
         }
     }
     StageTimer tm; tm.on = stats != nullptr; tm.pool = &c->event_pool;
-    int rc = enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true, &tm, stats != nullptr);
+    int rc = enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true, &tm, stats != nullptr && c->count_rays);
     if (rc != RT_OK) { double sm[ST_COUNT]; (void)hipStreamSynchronize(c->stream); tm.collect(sm); return rc; }
     if (!stats) return RT_OK;
     RT_HIP(c, hipStreamSynchronize(c->stream));
