@@ -297,7 +297,9 @@ def main():
     for _ in range(10):
         r.render_device(cfg, block.data_ptr()); r.synchronize()
     frame_latency_ms = (time.perf_counter() - t_lat) * 100.0
-    warm_steps = max(args.warmup, 2 * P)             # every context records its frame graph on its second frame
+    # every context records a frame graph on its second frame with the same output buffer; a pipeline alternates
+    # between two blocks, so it needs four frames before both graphs exist
+    warm_steps = max(args.warmup, (4 if pipelined else 2) * P)
     for _ in range(warm_steps):
         step()
     if world > 1:
