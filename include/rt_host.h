@@ -47,6 +47,10 @@ void rt_host_free_bvh(rt_host_bvh* b);
 int rt_host_read_ppm(const char* path, int32_t* width, int32_t* height, int32_t* maxval, int32_t** rgb);
 /* Image::writeImage, image.cpp:83-99: "P3\nW H\nmax\n", then per row "r g b " per pixel and "\n". */
 int rt_host_write_ppm(const char* path, int32_t width, int32_t height, int32_t maxval, const uint8_t* rgb);
+/* No counterpart in the reference (image.cpp:83-99 only writes text): the same image as binary "P6\nW H\n255\n" + bytes,
+ * 3 bytes per pixel instead of ~11 characters - for 4K frames, where the text form is ~100 MB.  Standard P6: the
+ * reference's own reader shifts P6 channels by one byte (image.cpp:44-60) and is not the intended consumer. */
+int rt_host_write_ppm_binary(const char* path, int32_t width, int32_t height, const uint8_t* rgb);
 void rt_host_free(void* p);
 
 /* Camera::convertPixelToRay with aperture 0 (camera.cpp:109-178): out6 = origin xyz, direction xyz. */

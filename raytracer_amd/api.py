@@ -114,7 +114,7 @@ API_SYMBOLS = ["rt_default_config", "rt_create", "rt_destroy", "rt_set_stream", 
                "rt_set_shard", "rt_local_tiles", "rt_max_tiles_per_rank", "rt_render", "rt_render_device",
                "rt_assemble_tiles", "rt_synchronize", "rt_last_error"]
 HOST_SYMBOLS = ["rt_host_parse_args", "rt_host_parse_scene", "rt_host_load_scene", "rt_host_free_scene",
-                "rt_host_build_bvh", "rt_host_free_bvh", "rt_host_read_ppm", "rt_host_write_ppm", "rt_host_free",
+                "rt_host_build_bvh", "rt_host_free_bvh", "rt_host_read_ppm", "rt_host_write_ppm", "rt_host_write_ppm_binary", "rt_host_free",
                 "rt_host_camera_ray"]
 
 _lib = None
@@ -155,6 +155,7 @@ def lib():
     L.rt_host_read_ppm.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.POINTER(C.c_int32))]
     L.rt_host_write_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    L.rt_host_write_ppm_binary.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]
     L.rt_host_free.argtypes = [C.c_void_p]; L.rt_host_free.restype = None
     L.rt_host_camera_ray.argtypes = [C.POINTER(Camera), C.c_float, C.c_float, C.POINTER(C.c_float)]
     L.rt_host_camera_ray.restype = None
@@ -407,9 +408,13 @@ def read_ppm(path: str) -> np.ndarray:
     return arr
 
 
-def write_ppm(path: str, img: np.ndarray, maxval: int = 255) -> None:
+def write_ppm(path: str, img: np.ndarray, maxval: int = 255, binary: bool = False) -> None:
+    """The reference's text form (image.cpp:83-99), or binary P6 (an extension) with binary=True."""
     img = np.ascontiguousarray(img, dtype=np.uint8)
-    rc = lib().rt_host_write_ppm(path.encode(), img.shape[1], img.shape[0], maxval, img.ctypes.data_as(C.c_void_p))
+    if binary:
+        rc = lib().rt_host_write_ppm_binary(path.encode(), img.shape[1], img.shape[0], img.ctypes.data_as(C.c_void_p))
+    else:
+        rc = lib().rt_host_write_ppm(path.encode(), img.shape[1], img.shape[0], maxval, img.ctypes.data_as(C.c_void_p))
     if rc != RT_OK:
         raise RtError(rc, f"cannot write {path}")
 

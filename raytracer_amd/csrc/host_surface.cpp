@@ -665,6 +665,16 @@ int rt_host_write_ppm(const char* path, int32_t width, int32_t height, int32_t m
     return RT_OK;
 }
 
+int rt_host_write_ppm_binary(const char* path, int32_t width, int32_t height, const uint8_t* rgb) {
+    if (!path || !rgb || width <= 0 || height <= 0) return RT_ERR_ARG;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { std::fprintf(stderr, "Failed to open the output file %s\n", path); return RT_ERR_IO; }
+    std::fprintf(f, "P6\n%d %d\n255\n", width, height);
+    const size_t n = (size_t)width * (size_t)height * 3;
+    const bool ok = std::fwrite(rgb, 1, n, f) == n;
+    return (std::fclose(f) == 0 && ok) ? RT_OK : RT_ERR_IO;
+}
+
 void rt_host_free(void* p) { std::free(p); }
 
 void rt_host_camera_ray(const rt_camera* c, float x, float y, float* out6);   // defined with the camera basis below

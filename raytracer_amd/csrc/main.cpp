@@ -2,7 +2,8 @@
 // banner and progress lines, scene from ../ASCII/scene.json, textures from ../Textures, image to ../Output.
 // The pixel loop between the two timer reads is one rt_render() call into the HIP pipeline.
 //
-// Extensions (not in the reference): --scene PATH, --textures DIR, --outdir DIR, --gpu N, --seed N, --fallback N.
+// Extensions (not in the reference): --scene PATH, --textures DIR, --outdir DIR, --gpu N, --seed N, --fallback N,
+// --p6 (binary PPM instead of the reference's text form).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,8 @@ int main(int argc, char* argv[]) {
     rt_host_parse_args(argc, argv, 1, &cfg, out_name, (int)sizeof out_name);
     std::string scene_path = "../ASCII/scene.json", tex_dir = "../Textures", out_dir = "../Output";
     int gpu = 0;
+    bool p6 = false;
+    for (int i = 1; i < argc; ++i) if (!std::strcmp(argv[i], "--p6")) p6 = true;
     for (int i = 1; i + 1 < argc; ++i) {
         if (!std::strcmp(argv[i], "--scene")) scene_path = argv[i + 1];
         else if (!std::strcmp(argv[i], "--textures")) tex_dir = argv[i + 1];
@@ -68,7 +71,8 @@ int main(int argc, char* argv[]) {
                 (unsigned long long)st.refraction_rays, st.ms_total);
 
     std::string out_path = out_dir + "/" + out_name;
-    rc = rt_host_write_ppm(out_path.c_str(), W, H, 255, rgb.data());   // raytracer.cpp:195; template maxval is 255
+    rc = p6 ? rt_host_write_ppm_binary(out_path.c_str(), W, H, rgb.data())
+            : rt_host_write_ppm(out_path.c_str(), W, H, 255, rgb.data());   // raytracer.cpp:195; template maxval is 255
     rt_host_free_bvh(&bvh);
     rt_destroy(ctx);
     rt_host_free_scene(hs);

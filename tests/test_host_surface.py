@@ -147,6 +147,9 @@ def test_ppm_reader_p3_p6_shift_and_writer(tmp_path):
     out = tmp_path / "o.ppm"
     api.write_ppm(str(out), np.array([[[0, 9, 10], [99, 100, 255]]], dtype=np.uint8))
     assert out.read_text() == "P3\n2 1\n255\n0 9 10 99 100 255 \n"
+    # binary form (an extension): standard P6 header, then the bytes
+    api.write_ppm(str(out), np.array([[[0, 9, 10], [99, 100, 255]]], dtype=np.uint8), binary=True)
+    assert out.read_bytes() == b"P6\n2 1\n255\n" + bytes([0, 9, 10, 99, 100, 255])
     # the committed textures read like the oracle reads them
     for name in ("checkerboard.ppm", "tex2.ppm"):
         a = api.read_ppm(str(cases.TEXTURES / name))
