@@ -274,6 +274,9 @@ def main():
     # Ray counts (identical every frame: the generator is counter based) and per-kernel device times.  The profiled
     # frame is enqueued behind four ordinary ones so that the GPU, not the host, paces it.
     st = r.render_device(cfg, block.data_ptr(), want_stats=True)     # ray counts (the counting kernel variants)
+    r.set_option("skip_unlit", 0)                                    # how many shadow rays the N.L <= 0 rule leaves untraced
+    shadow_all = r.render_device(cfg, block.data_ptr(), want_stats=True).shadow_rays
+    r.set_option("skip_unlit", 1)
     for _ in range(4):
         r.render_device(cfg, block.data_ptr())
     r.set_option("count_rays", 0)                                    # stage times with the kernels the timed frames run
@@ -337,7 +340,8 @@ def main():
                        "timing": "ms_per_step = timed wall clock / steps with frames_in_flight independent frames overlapping on the GPU; "
                                  "frame_ms_alone = one frame enqueued and waited for by itself",
                        "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3],
-                                          "hits_shaded": tot[5], "as_the_reference_would_trace_them": tot[0] + tot[4]},
+                                          "hits_shaded": tot[5], "as_the_reference_would_trace_them": tot[0] + tot[4],
+                                          "shadow_not_traced_because_the_surface_faces_away_from_the_light": (shadow_all - st.shadow_rays) if world == 1 else None},
                        "lit_fraction": lit},
             "roofline": roofline(st, args.workload, wl["scene"] != "random"),
         }

@@ -194,6 +194,9 @@ void* rt_get_stream(rt_ctx* ctx);
  * output pointer and stream, and replays it afterwards; default 1.  "overlap" = 0/1: whether frames rendered
  * without statistics trace the shadow rays of the primary hits on a second, internal stream while the render
  * stream traces the deeper recursion levels (joined before shading; the caller sees one stream); default 1.
+ * "skip_unlit" = 0/1: whether the shadow rays of a (hit, light) pair whose surface faces away from the light are left
+ * untraced (default 1; raytracer.cpp:322-336 multiplies their result by max(0, N.L) = 0, so frames are identical;
+ * rt_stats.shadow_rays counts traced rays, shadow_rays_ref what the reference traces).
  * "count_rays" = 0/1: whether rt_render_device with a statistics pointer counts rays (default 1) or only times the
  * stages, with the kernels plain frames use (the ray counts then read 0).
  * "max_grid" (all kernels) or "grid_primary" / "grid_secondary" / "grid_shadow" / "grid_shade" = workgroups per launch,

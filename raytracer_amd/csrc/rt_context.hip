@@ -193,6 +193,7 @@ struct rt_ctx {
     int file_sub_root = -1;
     int sub_min_group = RT_SUB_MIN_GROUP;    // groups above this size get a second-level hierarchy (rt_set_option)
     // workgroups per launch (more work than that is taken in rounds): primary extend, secondary extend, shadow, shade
+    bool skip_unlit = true;                  // see k_shadow: shadow rays whose result is multiplied by zero are not traced
     bool count_rays = true;                  // frames with statistics count rays (off: stage times only, at the speed of plain frames)
     // 0 = chosen per launch (see enqueue_frame)
     int grid_primary = 0, grid_secondary = 0, grid_shadow = 0, grid_shade = 0;
@@ -342,6 +343,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > (1 << 20)) return c->fail(RT_ERR_ARG, "%s must be 0..%d", name, 1 << 20);
         *which = (int)value; c->drop_graphs(); return RT_OK;
     }
+    if (std::strcmp(name, "skip_unlit") == 0) { c->skip_unlit = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "count_rays") == 0) { c->count_rays = value != 0; return RT_OK; }
     if (std::strcmp(name, "fast_samples") == 0) { c->fast_samples = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "overlap") == 0) { c->overlap = value != 0; c->drop_graphs(); return RT_OK; }
@@ -877,7 +879,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     // the retry is exact and, through the file-order set's hierarchy, cheap at any scene size: on unless opted out
     int fb = cfg->fallback; if (fb == 0) fb = 1;
     f.fallback_full = (fb == 1);
-    f.light_radius = cfg->light_radius; f.seed = cfg->seed; f.fast_samples = c->fast_samples ? 1 : 0; f.count_stats = count_stats ? 1 : 0;
+    f.light_radius = cfg->light_radius; f.seed = cfg->seed; f.fast_samples = c->fast_samples ? 1 : 0; f.count_stats = count_stats ? 1 : 0; f.skip_unlit = c->skip_unlit ? 1 : 0;
     f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y; f.n_local_tiles = (int)c->local_tiles.size(); f.local_tiles = c->d_local_tiles.p;
 
     const long long n_slots = (long long)c->local_tiles.size() * RT_TILE_PIX;

@@ -916,8 +916,19 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
             V3 p = mk(a.x, a.y, a.z);
             Ray sr; sr.time = a.w;
             Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
-            ++n_rays;
-            if (MODE == 0) {
+            // raytracer.cpp:322-336: the shadow factor only ever multiplies max(0, N.L).  Where the surface clearly faces
+            // away from the light that product is zero whatever the rays would find, so they are not traced (the count
+            // written is 0).  "Clearly": beyond any rounding of the shader's normalised N.L; NaNs fail the test and trace.
+            bool lit_side = true;
+            if (f.skip_unlit) {
+                const V3 nn = mk(b.x, b.y, b.z), Lr = mk(lt.x - p.x, lt.y - p.y, lt.z - p.z);
+                const float d = dot(nn, Lr);
+                lit_side = !(d < 0.0f && d * d > 1e-6f * dot(nn, nn) * dot(Lr, Lr));
+            }
+            if (lit_side) ++n_rays;
+            if (!lit_side) {
+                unblocked = false;
+            } else if (MODE == 0) {
                 V3 nrm = mk(b.x, b.y, b.z);
                 sr.d = normalise(mk(lt.x - p.x, lt.y - p.y, lt.z - p.z));
                 sr.o = p + nrm * 1e-2f;                                  // raytracer.cpp:515: unflipped geometric normal

@@ -78,6 +78,7 @@ struct DevFrame {
     float light_radius;
     uint32_t seed;
     int fast_samples;              // randomly drawn shadow rays use reciprocal arithmetic (distribution-level parity)
+    int skip_unlit;                // shadow rays of (hit, light) pairs whose N.L is clearly negative are not traced
     int count_stats;               // kernels add their ray counts to DevWork::stats (one atomic per workgroup and counter)
     // sharding
     int tiles_x, tiles_y, n_local_tiles;

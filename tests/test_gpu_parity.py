@@ -50,7 +50,8 @@ def test_deterministic_matches_oracle_and_reference_golden(scene, flags, texture
     assert st.primary_rays == ost.primary
     assert (st.shadow_rays_ref, st.reflection_rays_ref, st.refraction_rays_ref) == (ost.shadow, ost.reflection, ost.refraction)
     if "-r" not in flags and "-rd" not in flags:
-        assert st.shadow_rays == ost.shadow and st.reflection_rays == 0 and st.refraction_rays == 0
+        # (shadow rays towards a light the surface faces away from are not traced: their factor multiplies N.L = 0)
+        assert st.shadow_rays <= ost.shadow and st.reflection_rays == 0 and st.refraction_rays == 0
 
 
 def test_config1_full_frame_matches_reference_golden():
@@ -134,10 +135,10 @@ def test_non_power_of_two_shadow_samples_and_many_lights():
     img, st = api.render_scene_text(text, [])
     ref, ost = oracle.render(text, [])
     assert_close_images(img, ref, "3 lights, hard shadows")
-    assert st.shadow_rays == ost.shadow
+    assert st.shadow_rays_ref == ost.shadow and st.shadow_rays <= ost.shadow
     a, sa = api.render_scene_text(text, ["-ss", "-sss", "48"])       # 48 is not a power of two: atomic accumulation path
     b, sb = api.render_scene_text(text, ["-ss", "-sss", "64"])
-    assert sa.shadow_rays == sa.nodes_shaded * 3 * 48
+    assert sa.shadow_rays_ref == sa.nodes_shaded * 3 * 48 and sa.shadow_rays % 48 == 0 and 0 < sa.shadow_rays <= sa.shadow_rays_ref
     assert psnr(a, b) > 35.0
 
 
@@ -232,6 +233,35 @@ def test_reciprocal_arithmetic_on_shadow_samples_moves_almost_no_sample(scene, n
     # a flipped sample moves a pixel by up to 255 / ss_samples levels; grazing rays that start 0.001 along the light
     # direction from a surface (raytracer.cpp:549) are the rounding-sensitive ones, in the reference as well
     assert psnr(got[0][0], got[1][0]) > 50.0
+
+
+@pytest.mark.parametrize("scene,flags", [("ref", []), ("ref", ["-r", "-rd", "3", "-ss", "-sss", "8"]), ("ref", ["-ss", "-sss", "5", "-u"]),
+                                         ("glass_tex", ["-rd", "2", "-grs", "1", "-t"]), ("bvh5", []), ("cube_mb", ["-m", "-mbs", "2", "-aa", "-aas", "2"])])
+def test_untraced_shadow_rays_of_unlit_sides_change_no_pixel(scene, flags, textures_dir):
+    """raytracer.cpp:322-336 multiplies the shadow factor by max(0, N.L) only, so the shadow rays of a (hit, light) pair
+    whose surface clearly faces away from the light are not traced (option skip_unlit, default on).  Against tracing
+    them all: bit-identical frames (the generator is counter based, nothing shifts), the reference-equivalent counts
+    unchanged, fewer rays traced; with the option off the traced count is the oracle's."""
+    cfg, _ = api.parse_args(flags)
+    cfg.seed = 3
+    text = cases.SCENES[scene]()
+    ls = api.LoadedScene(text, cfg, textures_dir)
+    got = []
+    for skip in (1, 0):
+        r = api.Renderer(0); r.set_option("skip_unlit", skip); r.upload(ls, with_bvh=bool(cfg.bvh))
+        img, st = r.render(cfg)
+        got.append((img, st))
+        r.close()
+    ls.close()
+    assert got[0][0].max() > 0 and np.array_equal(got[0][0], got[1][0])
+    on, off = got[0][1], got[1][1]
+    assert (on.shadow_rays_ref, on.reflection_rays, on.refraction_rays, on.nodes_shaded) == (off.shadow_rays_ref, off.reflection_rays, off.refraction_rays, off.nodes_shaded)
+    assert 0 < on.shadow_rays < off.shadow_rays
+    if not any(x in flags for x in ("-ss", "-aa", "-m", "-dof", "-gr")):
+        _, ost = oracle.render(text, flags, textures_dir)
+        assert off.shadow_rays_ref == ost.shadow
+        if "-r" not in flags and "-rd" not in flags:
+            assert off.shadow_rays == ost.shadow
 
 
 # ---- large scenes: the second-level hierarchy ----------------------------------------------------------------
