@@ -30,7 +30,7 @@ def main():
     res = {}
     for wl in todo:
         heavy = wl == "config4"
-        steps, warmup = (2, 1) if heavy else (20, 3)
+        steps, warmup = (2, 1) if heavy else ((20, 3) if wl == "cube_mb" else (100, 8))
         t0 = time.time()
         one = run(wl, 1, steps, warmup)
         entry = {"workload": one["config"]["workload"], "steps": steps, "rays_per_frame": one["config"]["rays_per_frame"],
