@@ -50,6 +50,14 @@ def _worker(rank: int, world: int, port: int, img: np.ndarray, out_path: str):
         np.save(out_path, api.assemble_tiles_numpy(blocks, img.shape[1], img.shape[0]))
     else:
         assert gathered is None
+    # the asynchronous form the frame pipeline uses: two gathers in flight into preallocated buffers, waited in order
+    outs = [torch.empty(world * block.numel(), dtype=torch.uint8) if rank == 0 else None for _ in range(2)]
+    second = block.flip(0).contiguous()
+    h0 = rdist.gather_blocks_async(block, outs[0]); h1 = rdist.gather_blocks_async(second, outs[1])
+    h0.wait(); h1.wait()
+    if rank == 0:
+        assert torch.equal(outs[0], gathered)
+        assert torch.equal(outs[1].view(world, -1)[rank], second) and not torch.equal(outs[0], outs[1])
     dist.barrier()
     dist.destroy_process_group()
 
