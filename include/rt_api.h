@@ -173,7 +173,9 @@ typedef struct rt_ctx rt_ctx;
 void rt_default_config(rt_config* cfg);
 
 /* Creates a context on HIP device `device_id`.  workspace_bytes = upper bound for the ray queues and the
- * hit-tree arena (0 = default of 4 GiB); it is allocated lazily by the first render and grown never. */
+ * hit-tree arena (0 = default of 4 GiB); the work buffers are allocated by the first render and
+ * re-allocated (never beyond that bound) when a later frame needs more: deeper recursion, more lights, a larger film.
+ * A re-allocation waits for the frames in flight and drops every recorded frame graph. */
 rt_ctx* rt_create(int device_id, uint64_t workspace_bytes);
 void rt_destroy(rt_ctx* ctx);
 

@@ -15,7 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <numeric>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -359,12 +361,12 @@ int rt_synchronize(rt_ctx* c) {
     return RT_OK;
 }
 
-int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
+static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
     if (!c || !sc) return RT_ERR_ARG;
-    if (sc->n_lights < 0 || sc->n_spheres < 0 || sc->n_cubes < 0 || sc->n_planes < 0 || sc->n_textures < 0)
+    if (sc->n_lights < 0 || sc->n_spheres < 0 || sc->n_cubes < 0 || sc->n_planes < 0 || sc->n_textures < 0 || sc->n_plane_verts < 0)
         return c->fail(RT_ERR_ARG, "negative count in scene");
     if ((sc->n_lights && !sc->lights) || (sc->n_spheres && !sc->spheres) || (sc->n_cubes && !sc->cubes) ||
-        (sc->n_planes && (!sc->planes || !sc->plane_verts)) || (sc->n_textures && !sc->textures))
+        (sc->n_planes && !sc->planes) || (sc->n_plane_verts && !sc->plane_verts) || (sc->n_textures && !sc->textures))
         return c->fail(RT_ERR_ARG, "null array with non-zero count in scene");
     if (!(sc->camera.res_x >= 1.0f && sc->camera.res_y >= 1.0f && sc->camera.res_x <= 65536.0f && sc->camera.res_y <= 65536.0f))
         return c->fail(RT_ERR_ARG, "film resolution out of range");
@@ -404,7 +406,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
         std::vector<char> claimed((size_t)sc->n_plane_verts, 0);
         for (int i = 0; i < np; ++i) {
             const rt_plane& p = sc->planes[i];
-            if (p.n_verts < 3 || p.n_verts > 0xffff || p.first_vert < 0 || p.first_vert + p.n_verts > sc->n_plane_verts)
+            if (p.n_verts < 3 || p.n_verts > 0xffff || p.first_vert < 0 || (long long)p.first_vert + p.n_verts > (long long)sc->n_plane_verts)
                 return c->fail(RT_ERR_ARG, "plane %d: vertex range out of bounds", i);
             for (int k = 0; k < p.n_verts; ++k) {
                 if (claimed[(size_t)p.first_vert + k]) return c->fail(RT_ERR_ARG, "plane %d: vertex range overlaps another plane's", i);
@@ -420,7 +422,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
     rt_parallel_for((size_t)np, 2048, [&](size_t lo, size_t hi, int) {
         for (size_t i = lo; i < hi; ++i) {
             const rt_plane& p = sc->planes[i];
-            if (p.n_verts < 3 || p.n_verts > 0xffff || p.first_vert < 0 || p.first_vert + p.n_verts > sc->n_plane_verts) { bad_plane = (int)i; continue; }
+            if (p.n_verts < 3 || p.n_verts > 0xffff || p.first_vert < 0 || (long long)p.first_vert + p.n_verts > (long long)sc->n_plane_verts) { bad_plane = (int)i; continue; }
             const float* v = sc->plane_verts + (size_t)p.first_vert * 3;
             std::vector<int> ord = winding_order(v, p.n_verts, p.normal);
             for (int k = 0; k < p.n_verts; ++k)
@@ -620,7 +622,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
     return RT_OK;
 }
 
-int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const int32_t* prim_ids, int32_t n_prim_ids) {
+static int upload_bvh_impl(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const int32_t* prim_ids, int32_t n_prim_ids) {
     if (!c) return RT_ERR_ARG;
     if (!c->have_scene) return c->fail(RT_ERR_STATE, "rt_upload_bvh before rt_upload_scene");
     RT_HIP(c, hipSetDevice(c->device));
@@ -798,6 +800,19 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
     return RT_OK;
 }
 
+// The uploads build host-side vectors sized by the caller's counts: nothing may be thrown across the C boundary.
+int rt_upload_scene(rt_ctx* c, const rt_scene* sc) {
+    try { return upload_scene_impl(c, sc); }
+    catch (const std::bad_alloc&) { c->have_scene = false; return c->fail(RT_ERR_ARG, "rt_upload_scene: out of host memory for a scene of this size"); }
+    catch (const std::exception& e) { c->have_scene = false; return c->fail(RT_ERR_ARG, "rt_upload_scene: %s", e.what()); }
+}
+
+int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const int32_t* prim_ids, int32_t n_prim_ids) {
+    try { return upload_bvh_impl(c, nodes, n_nodes, prim_ids, n_prim_ids); }
+    catch (const std::bad_alloc&) { c->have_bvh = false; return c->fail(RT_ERR_ARG, "rt_upload_bvh: out of host memory for a tree of this size"); }
+    catch (const std::exception& e) { c->have_bvh = false; return c->fail(RT_ERR_ARG, "rt_upload_bvh: %s", e.what()); }
+}
+
 int rt_set_shard(rt_ctx* c, int32_t rank, int32_t world) {
     if (!c) return RT_ERR_ARG;
     if (world < 1 || rank < 0 || rank >= world) return c->fail(RT_ERR_ARG, "rank %d of world %d", rank, world);
@@ -851,6 +866,88 @@ struct StageTimer {
     }
 };
 
+// ---- work plan: batch size, per-level regions and buffer capacities of one frame ---------------------------------
+// Worst-case hits per primary sample at every recursion level decide the capacities, so a buffer cannot overflow
+// (the kernels still check).  Fan-out of a hit: with glossy reflection, gr_samples reflection rays and one refraction
+// ray; with soft shadows (and no glossy reflection) the first reflection of a path is traced gr_samples times (see
+// k_extend: each of the reference's identical rays owns its shadow samples), later ones once; otherwise one each.
+struct WorkPlan {
+    int D = 0, R = 1;
+    long long B = 0;                       // pixel slots per batch
+    bool fanout = false, grouped = true;
+    long long node_off[RT_MAX_LEVELS + 2], link_off[RT_MAX_LEVELS + 2], rcap[RT_MAX_LEVELS + 2];
+    size_t cap_nodes = 0, cap_links = 0, cap_rays = 0, cap_pix = 0, cap_shadow = 0;
+    long long widest_chunks[RT_MAX_LEVELS + 2];
+};
+
+// bytes of the per-batch buffers of a plan, each rounded up to 256
+static size_t plan_bytes(const WorkPlan& p, bool textures) {
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return 4 * al(p.cap_rays * 16) + 4 * al(p.cap_nodes * 16) + (textures ? al(p.cap_nodes * 8) : 0) + al(p.cap_pix * 4) +
+           al(p.cap_shadow * 4) + al(p.cap_links * 4);
+}
+
+static int make_plan(rt_ctx* c, const rt_config* cfg, int D, int L, bool textures, long long n_slots, unsigned long long budget, WorkPlan& p) {
+    const long long gr = cfg->gr_samples;
+    const long long refl = c->any_reflective ? 1 : 0, transp = c->any_transparent ? 1 : 0;
+    double npp[RT_MAX_LEVELS + 2];         // worst-case hits per primary sample at level d
+    {
+        double a = 1.0, b = 0.0;           // hits whose path has / has not yet had its gr_samples-fold reflection
+        const bool replicate = cfg->soft_shadows && !cfg->glossy_reflect;
+        for (int d = 0; d <= D; ++d) {
+            npp[d] = a + b;
+            if (cfg->glossy_reflect) { a = a * (double)(refl * gr + transp); }
+            else if (replicate) { const double a2 = a * (double)transp, b2 = a * (double)(refl * gr) + b * (double)(refl + transp); a = a2; b = b2; }
+            else { a = a * (double)(refl + transp); }
+        }
+    }
+    p.D = D;
+    p.fanout = D > 0 && (refl || transp);
+    double nodes_per = 0, widest = 1;
+    for (int d = 0; d <= D; ++d) { nodes_per += npp[d]; widest = std::max(widest, npp[d]); if (!p.fanout) break; }
+    const double links_per = nodes_per - 1.0;
+    p.grouped = !cfg->soft_shadows || (cfg->ss_samples <= 64 && (cfg->ss_samples & (cfg->ss_samples - 1)) == 0);
+    const double bytes_per = nodes_per * (16.0 * 4 + (textures ? 8 : 0) + 4.0 * std::max(L, 1)) + 4.0 + links_per * 4.0 +
+                             (p.fanout ? 2.0 * widest * 32.0 : 0.0);
+    // (1/64 of the budget covers the rounding of the regions' capacities, see below)
+    long long B = (long long)((double)budget * (63.0 / 64.0) / bytes_per);
+    B = std::min(B, n_slots);
+    // int32 indexing inside the kernels
+    B = std::min(B, (long long)(2.0e9 / std::max(1.0, nodes_per * std::max(1, L) * (cfg->soft_shadows ? cfg->ss_samples : 1))));
+    for (int attempt = 0; attempt < 12; ++attempt) {
+        if (B >= RT_TILE_PIX) B -= B % RT_TILE_PIX; else B -= B % 64;
+        if (B < 64) return c->fail(RT_ERR_CAPACITY, "a work area of %llu bytes cannot hold one wavefront of samples at depth %d (up to %.0f hits per sample)",
+                                   budget, D, nodes_per);
+        // Per-level parts of the node and link arenas, each cut into R regions with their own counters.  A region of
+        // level 0 receives the hits of every R-th chunk of 256 primary rays; a region of level d + 1 the rays spawned by
+        // the same region of level d.  R = RT_REGIONS once a batch has 64 chunks per region (the rounding of the
+        // capacities then costs under 1/64), fewer for small batches, which issue few atomics anyway.
+        const long long chunks0 = (B + RT_BLOCK - 1) / RT_BLOCK;
+        int R = 1;
+        while (R < RT_REGIONS && chunks0 >= 64ll * (2 * R)) R *= 2;
+        long long widest_rcap = 0;
+        const long long rcap0 = ((chunks0 + R - 1) / R) * RT_BLOCK;
+        std::memset(p.node_off, 0, sizeof p.node_off); std::memset(p.link_off, 0, sizeof p.link_off); std::memset(p.rcap, 0, sizeof p.rcap);
+        for (int d = 0; d <= D; ++d) {
+            p.rcap[d] = (long long)((double)rcap0 * (p.fanout || d == 0 ? npp[d] : 0.0)) + (d ? 64 : 0);
+            p.node_off[d + 1] = p.node_off[d] + R * p.rcap[d];
+            if (d >= 1) { p.link_off[d + 1] = p.link_off[d] + R * p.rcap[d]; widest_rcap = std::max(widest_rcap, p.rcap[d]); }
+        }
+        p.link_off[D + 2] = p.link_off[D + 1];
+        p.R = R; p.B = B;
+        p.cap_nodes = (size_t)p.node_off[D + 1];
+        p.cap_links = (size_t)p.link_off[D + 1] + 64;
+        p.cap_rays = p.fanout ? (size_t)(R * widest_rcap) + 64 : 64;
+        p.cap_pix = (size_t)(R * p.rcap[0]);                             // n_pix is indexed by the level-0 node
+        p.cap_shadow = p.cap_nodes * (size_t)std::max(L, 1);
+        if (p.cap_nodes > 0x7fffffffull || p.cap_links > 0x7fffffffull) return c->fail(RT_ERR_CAPACITY, "batch too large for 32-bit node indices");
+        const size_t need = plan_bytes(p, textures);
+        if (need <= budget) return RT_OK;
+        B = (long long)((double)B * ((double)budget / (double)need) * 0.97);      // the estimate was short: smaller batches
+    }
+    return c->fail(RT_ERR_CAPACITY, "no batch size fits a work area of %llu bytes", budget);
+}
+
 // Enqueue one frame.  out_dev: device buffer in the layout rt_render_device documents.
 static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev, bool want_stats_zero, StageTimer* tm, bool count_stats = true) {
     if (!c->have_scene) return c->fail(RT_ERR_STATE, "render before rt_upload_scene");
@@ -883,70 +980,52 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y; f.n_local_tiles = (int)c->local_tiles.size(); f.local_tiles = c->d_local_tiles.p;
 
     const long long n_slots = (long long)c->local_tiles.size() * RT_TILE_PIX;
-    // Worst-case fan-out per hit: every hit reflects (gr_samples rays when glossy, one otherwise) and refracts.
-    const long long k_refl = c->any_reflective ? (cfg->glossy_reflect ? cfg->gr_samples : 1) : 0;
-    const long long k = D > 0 ? k_refl + (c->any_transparent ? 1 : 0) : 0;
-    // per primary sample: nodes = sum_{d<=D} k^d, links = sum_{1<=d<=D} k^d, widest level = k^D (or 1)
-    double nodes_per = 0, widest = 1, pw = 1;
-    for (int d = 0; d <= D; ++d) { nodes_per += pw; widest = std::max(widest, pw); pw *= (double)k; if (k == 0) break; }
-    double links_per = nodes_per - 1.0;
-    const bool grouped = !cfg->soft_shadows || (cfg->ss_samples <= 64 && (cfg->ss_samples & (cfg->ss_samples - 1)) == 0);
-    double bytes_per = nodes_per * (16.0 * 4 + (f.textures ? 8 : 0) + 4.0 * std::max(L, 1)) + 4.0 + links_per * 4.0 +
-                       (k > 0 ? 2.0 * widest * 32.0 : 0.0);
-    // (1/64 of the budget covers the rounding of the regions' capacities, see below)
-    long long B = (long long)((double)c->workspace_limit * (63.0 / 64.0) / bytes_per);
-    B = std::min(B, n_slots);
-    // int32 indexing inside the kernels
-    B = std::min(B, (long long)(2.0e9 / std::max(1.0, nodes_per * std::max(1, L) * (cfg->soft_shadows ? cfg->ss_samples : 1))));
-    if (B >= RT_TILE_PIX) B -= B % RT_TILE_PIX; else B -= B % 64;
-    if (B < 64) return c->fail(RT_ERR_CAPACITY, "workspace of %llu bytes cannot hold one wavefront of samples at depth %d with fan-out %lld",
-                               (unsigned long long)c->workspace_limit, D, k);
-    // Per-level parts of the node and link arenas, each cut into R regions with their own counters.  A region of
-    // level 0 receives the hits of every R-th chunk of 256 primary rays; a region of level d + 1 the rays spawned by
-    // the same region of level d, at most k per hit.  R = RT_REGIONS once a batch has 64 chunks per region (the
-    // rounding of the capacities then costs under 1/64), fewer for small batches, which issue few atomics anyway.
-    std::vector<long long> node_off((size_t)D + 3, 0), link_off((size_t)D + 3, 0), rcap((size_t)D + 3, 0);
-    long long widest_rcap = 0;
-    const long long chunks0 = (B + RT_BLOCK - 1) / RT_BLOCK;
-    int R = 1;
-    while (R < RT_REGIONS && chunks0 >= 64ll * (2 * R)) R *= 2;
-    {
-        double per = 1.0;
-        const long long rcap0 = ((chunks0 + R - 1) / R) * RT_BLOCK;
-        for (int d = 0; d <= D; ++d) {
-            rcap[(size_t)d] = (long long)((double)rcap0 * per) + (d ? 64 : 0);
-            node_off[(size_t)d + 1] = node_off[(size_t)d] + R * rcap[(size_t)d];
-            if (d >= 1) { link_off[(size_t)d + 1] = link_off[(size_t)d] + R * rcap[(size_t)d]; widest_rcap = std::max(widest_rcap, rcap[(size_t)d]); }
-            per *= (double)k;
-        }
-        link_off[(size_t)D + 2] = link_off[(size_t)D + 1];
+    if (n_slots == 0) {
+        // more ranks than tiles: this rank's block is all padding
+        RT_HIP(c, hipSetDevice(c->device));
+        const size_t pad = c->world > 1 ? (size_t)c->max_tiles * RT_TILE_PIX * 3 : (size_t)f.width * (size_t)f.height * 3;
+        if (pad) RT_HIP(c, hipMemsetAsync(out_dev, 0, pad, c->stream));
+        if (want_stats_zero) { RT_HIP(c, c->stats.resize(RT_S_TOTAL)); RT_HIP(c, hipMemsetAsync(c->stats.p, 0, RT_S_TOTAL * sizeof(unsigned long long), c->stream)); }
+        c->err.clear(); c->last_batches = 0;
+        return RT_OK;
     }
-    const size_t cap_nodes = (size_t)node_off[(size_t)D + 1];
-    const size_t cap_links = (size_t)link_off[(size_t)D + 1] + 64;
-    const size_t cap_rays = k > 0 ? (size_t)(R * widest_rcap) + 64 : 64;
-    const size_t cap_pix = (size_t)(R * rcap[0]);                        // n_pix is indexed by the level-0 node
-    if (cap_nodes > 0x7fffffffull || cap_links > 0x7fffffffull) return c->fail(RT_ERR_CAPACITY, "batch too large for 32-bit node indices");
-
     hipStream_t s = c->stream;
     RT_HIP(c, hipSetDevice(c->device));
-    const bool grow = cap_nodes > c->n_a.n || cap_links > c->link.n || cap_rays > c->q_a[0].n || (size_t)n_slots > c->accum.n ||
-                      (f.textures && cap_nodes > c->n_uv.n) || cap_nodes * (size_t)std::max(L, 1) > c->shadow.n || cap_pix > c->n_pix.n;
-    if (grow) RT_HIP(c, hipStreamSynchronize(s));
-    for (int q = 0; q < 2; ++q) { RT_HIP(c, c->q_a[q].resize(cap_rays)); RT_HIP(c, c->q_b[q].resize(cap_rays)); }
-    RT_HIP(c, c->n_a.resize(cap_nodes)); RT_HIP(c, c->n_b.resize(cap_nodes)); RT_HIP(c, c->n_c.resize(cap_nodes));
-    RT_HIP(c, c->n_col.resize(cap_nodes));
-    if (f.textures) RT_HIP(c, c->n_uv.resize(cap_nodes));
-    RT_HIP(c, c->n_pix.resize(cap_pix));
-    RT_HIP(c, c->shadow.resize(cap_nodes * (size_t)std::max(L, 1)));
-    RT_HIP(c, c->link.resize(cap_links));
-    RT_HIP(c, c->accum.resize((size_t)n_slots));
-    RT_HIP(c, c->ctr.resize(RT_C_TOTAL));
-    RT_HIP(c, c->stats.resize(RT_S_TOTAL));
+
+    const unsigned long long budget = c->workspace_limit;
+    WorkPlan plan;
+    RT_TRY(make_plan(c, cfg, D, L, f.textures != 0, n_slots, budget, plan));
+    const long long B = plan.B;
+    const int R = plan.R;
+    const bool grouped = plan.grouped;
+    const size_t cap_nodes = plan.cap_nodes, cap_links = plan.cap_links, cap_rays = plan.cap_rays, cap_pix = plan.cap_pix;
+    const long long* node_off = plan.node_off; const long long* link_off = plan.link_off; const long long* rcap = plan.rcap;
 
     DevWork w; std::memset(&w, 0, sizeof w);
-    for (int q = 0; q < 2; ++q) { w.q_a[q] = c->q_a[q].p; w.q_b[q] = c->q_b[q].p; }
-    w.n_a = c->n_a.p; w.n_b = c->n_b.p; w.n_c = c->n_c.p; w.n_uv = c->n_uv.p; w.n_col = c->n_col.p; w.n_pix = c->n_pix.p;
-    w.shadow = c->shadow.p; w.link = c->link.p; w.accum = c->accum.p; w.ctr = c->ctr.p; w.stats = c->stats.p;
+    {
+        const bool grow = cap_nodes > c->n_a.n || cap_links > c->link.n || cap_rays > c->q_a[0].n || (size_t)n_slots > c->accum.n ||
+                          (f.textures && cap_nodes > c->n_uv.n) || plan.cap_shadow > c->shadow.n || cap_pix > c->n_pix.n;
+        if (grow) {
+            // Recorded frames hold the addresses of the buffers that are about to be freed: drop every recording before any
+            // reallocation, and wait for the frames still in flight on either stream.
+            c->drop_graphs();
+            RT_HIP(c, hipStreamSynchronize(s));
+            if (c->aux_stream) RT_HIP(c, hipStreamSynchronize(c->aux_stream));
+        }
+        for (int q = 0; q < 2; ++q) { RT_HIP(c, c->q_a[q].resize(cap_rays)); RT_HIP(c, c->q_b[q].resize(cap_rays)); }
+        RT_HIP(c, c->n_a.resize(cap_nodes)); RT_HIP(c, c->n_b.resize(cap_nodes)); RT_HIP(c, c->n_c.resize(cap_nodes));
+        RT_HIP(c, c->n_col.resize(cap_nodes));
+        if (f.textures) RT_HIP(c, c->n_uv.resize(cap_nodes));
+        RT_HIP(c, c->n_pix.resize(cap_pix));
+        RT_HIP(c, c->shadow.resize(plan.cap_shadow));
+        RT_HIP(c, c->link.resize(cap_links));
+        RT_HIP(c, c->accum.resize((size_t)n_slots));
+        RT_HIP(c, c->ctr.resize(RT_C_TOTAL));
+        RT_HIP(c, c->stats.resize(RT_S_TOTAL));
+        for (int q = 0; q < 2; ++q) { w.q_a[q] = c->q_a[q].p; w.q_b[q] = c->q_b[q].p; }
+        w.n_a = c->n_a.p; w.n_b = c->n_b.p; w.n_c = c->n_c.p; w.n_uv = c->n_uv.p; w.n_col = c->n_col.p; w.n_pix = c->n_pix.p;
+        w.shadow = c->shadow.p; w.link = c->link.p; w.accum = c->accum.p; w.ctr = c->ctr.p; w.stats = c->stats.p;
+    }
     w.cap_nodes = (unsigned)cap_nodes;
     for (int d = 0; d <= D + 2 && d < RT_MAX_LEVELS; ++d) {
         w.node_off[d] = (int)node_off[(size_t)std::min(d, D + 1)]; w.link_off[d] = (int)link_off[(size_t)d];
@@ -961,7 +1040,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     const bool direct = S == 1 && B >= n_slots && ((uintptr_t)out_dev % 16) == 0;
     f.direct_out = direct ? out_dev : nullptr; f.direct_tile_major = tile_major;
     if (direct) rt_launch_begin_frame(s, w, out_dev, out_bytes, want_stats_zero);
-    else rt_launch_begin_frame(s, w, c->accum.p, (size_t)n_slots * sizeof(float4), want_stats_zero);
+    else rt_launch_begin_frame(s, w, w.accum, (size_t)n_slots * sizeof(float4), want_stats_zero);
 
     unsigned long long batches = 0;
     StageTimer local_tm; if (!tm) { tm = &local_tm; tm->pool = &c->event_pool; }
@@ -969,7 +1048,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     const unsigned long long n_batches = (unsigned long long)((n_slots + B - 1) / B) * (unsigned long long)S;
     if (n_batches > 64) tm->on = false;
     tm->reserve((size_t)n_batches * (size_t)(2 * D + 4) * 2 + 2);
-    const bool split = L > 0 && D >= 1 && k > 0;                 // shadow rays in two launches: level 0, then the rest
+    const bool split = L > 0 && D >= 1 && plan.fanout;                 // shadow rays in two launches: level 0, then the rest
     const bool overlap = split && c->overlap && !tm->on;         // stage times are only meaningful on one stream
     for (long long begin = 0; begin < n_slots; begin += B) {
         const int count = (int)std::min<long long>(B, n_slots - begin);
@@ -993,8 +1072,8 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         const int grid0 = std::max(1, std::min(g_primary, chunks0_batch));
         for (int smp = 0; smp < S; ++smp) {
             f.sample = smp;
-            if (batches > 0) RT_HIP(c, hipMemsetAsync(c->ctr.p, 0, RT_C_TOTAL * sizeof(int), s));   // counters of the batch
-            if (!grouped) RT_HIP(c, hipMemsetAsync(c->shadow.p, 0, cap_nodes * (size_t)std::max(L, 1) * sizeof(float), s));
+            if (batches > 0) RT_HIP(c, hipMemsetAsync(w.ctr, 0, RT_C_TOTAL * sizeof(int), s));   // counters of the batch
+            if (!grouped) RT_HIP(c, hipMemsetAsync(w.shadow, 0, plan.cap_shadow * sizeof(float), s));
             for (int level = 0; level <= D; ++level) {
                 tm->begin(level == 0 ? ST_EXTEND_PRIMARY : ST_EXTEND_SECONDARY);
                 rt_launch_extend(s, c->scene, f, w, level, level == 0 ? grid0 : g_secondary(level));
@@ -1058,6 +1137,7 @@ int rt_render_device(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev, rt_stat
     auto t0 = std::chrono::steady_clock::now();
     const long long spp = (long long)(cfg->anti_aliasing ? cfg->aa_samples : 1) * (cfg->dof ? cfg->dof_samples : 1) *
                           (cfg->motion_blur ? cfg->mb_samples : 1);
+    bool remember = false;
     if (!stats && c->use_graphs && spp >= 1 && spp <= 64) {
         rt_ctx::FrameGraph* g = nullptr;
         for (auto& e : c->graphs)
@@ -1068,8 +1148,14 @@ int rt_render_device(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev, rt_stat
             RT_HIP(c, hipSetDevice(c->device));
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const unsigned long long gen = c->generation;
                 int rc = enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true, nullptr, false);
                 hipError_t e = hipStreamEndCapture(c->stream, &graph);
+                if (gen != c->generation) {                  // the list was dropped under us (cannot happen: the buffers exist)
+                    if (graph) (void)hipGraphDestroy(graph);
+                    (void)hipGetLastError();
+                    return rc != RT_OK ? rc : c->fail(RT_ERR_STATE, "work buffers changed while a frame was being recorded");
+                }
                 if (rc == RT_OK && e == hipSuccess && graph && c->last_batches <= 64 &&
                     hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
                     (void)hipGraphDestroy(graph);
@@ -1081,15 +1167,18 @@ int rt_render_device(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev, rt_stat
                 (void)hipGetLastError();
                 if (rc != RT_OK) return rc;
             } else (void)hipGetLastError();
-        } else if (!g) {
-            if (c->graphs.size() >= 8) { if (c->graphs.front().exec) (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
-            rt_ctx::FrameGraph e{}; e.cfg = *cfg; e.out = rgb_out_dev; e.stream = c->stream; e.generation = c->generation; e.warm = true; e.exec = nullptr;
-            c->graphs.push_back(e);
-        }
+        } else if (!g) remember = true;
     }
     StageTimer tm; tm.on = stats != nullptr; tm.pool = &c->event_pool;
     int rc = enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true, &tm, stats != nullptr && c->count_rays);
     if (rc != RT_OK) { double sm[ST_COUNT]; (void)hipStreamSynchronize(c->stream); tm.collect(sm); return rc; }
+    if (remember) {
+        // first request of this frame: its buffers exist now (a frame that had to grow them dropped every older
+        // recording on the way), so the next request can be recorded without allocating or synchronising
+        if (c->graphs.size() >= 8) { if (c->graphs.front().exec) (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
+        rt_ctx::FrameGraph e{}; e.cfg = *cfg; e.out = rgb_out_dev; e.stream = c->stream; e.generation = c->generation; e.warm = true; e.exec = nullptr;
+        c->graphs.push_back(e);
+    }
     if (!stats) return RT_OK;
     RT_HIP(c, hipStreamSynchronize(c->stream));
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

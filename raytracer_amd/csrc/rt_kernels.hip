@@ -714,13 +714,14 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
         const int rg = PRIMARY ? (g & (w.regions - 1)) : rg_next;                // region this round allocates in
         bool active = PRIMARY ? i < f.pix_count : i >= 0;
         Ray r; uint32_t path = 0, mult = 1; int slot = 0;
+        bool replicated = false;            // an ancestor's reflection was already traced gr_samples times (soft shadows)
         r.o = mk(0, 0, 0); r.d = mk(0, 0, 1); r.time = 0.0f;
         if (active) {
             if (PRIMARY) active = generate_primary(f, i, r, path, slot);
             else {
                 float4 a = qa_next, b = qb_next;
                 r.o = mk(a.x, a.y, a.z); r.d = mk(a.w, b.x, b.y); r.time = 0.0f;   // secondary rays carry time 0 (ray.h:13)
-                path = (uint32_t)f2i(b.z); mult = (uint32_t)f2i(b.w);
+                path = (uint32_t)f2i(b.z); mult = (uint32_t)f2i(b.w) & 0x7fffffffu; replicated = (f2i(b.w) >> 31) & 1;
             }
         }
         if (!PRIMARY && g + (int)gridDim.x < n_chunks) {
@@ -750,8 +751,13 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
                     rd = normalise(mk(r.d.x - 2.0f * incoming * N.x, r.d.y - 2.0f * incoming * N.y, r.d.z - 2.0f * incoming * N.z));
                     glossy = f.glossy && m0.w > 0.0f;
                     if (glossy) gloss_angle = (float)((double)smax(0.01f, (1.0f - smin(1.0f, m0.w / 128.0f))) * (M_PI / 6.0));
-                    // without glossy perturbation all gr_samples rays are identical: trace one, replay the sum at resolve
-                    n_reflect = glossy ? f.gr_samples : 1;
+                    // Without glossy perturbation all gr_samples rays are identical: trace one, replay the sum at resolve.
+                    // With soft shadows the reference's identical rays still differ in what follows them: each hit draws
+                    // its own shadow samples (raytracer.cpp:330-332 under :400-432) and is clamped on its own.  The first
+                    // reflection of a path is therefore traced gr_samples times for real (distinct path ids, so distinct
+                    // sample sets); below it, where a contribution carries reflectivity^2 or less, identical rays are
+                    // traced once again (the reference would trace gr_samples^depth of them).
+                    n_reflect = (glossy || (f.soft_shadows && !replicated)) ? f.gr_samples : 1;
                 }
                 if (transparency > 0) {                                  // raytracer.cpp:444-497
                     float n1 = 1.0f, n2 = ior;
@@ -811,7 +817,8 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
             const float EPS = 1e-4f;
             // multiplicity of the children: each of the reference's gr_samples copies of a deduplicated ray
             unsigned long long cm = (unsigned long long)mult * (unsigned)(n_reflect == 1 ? f.gr_samples : 1);
-            const uint32_t child_mult = cm > 0xffffffffull ? 0xffffffffu : (uint32_t)cm;
+            const uint32_t flag_refl = (replicated || (f.soft_shadows && !glossy)) ? 0x80000000u : 0u;
+            const uint32_t child_mult = (cm > 0x7fffffffull ? 0x7fffffffu : (uint32_t)cm) | flag_refl;
             for (int j = 0; j < n_reflect; ++j) {                        // raytracer.cpp:415-421
                 V3 dir = rd;
                 uint32_t cpath = mix32(path * 0x9E3779B1u + (uint32_t)j + 1u);
@@ -827,7 +834,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
                 V3 org = h.p + fd * EPS;
                 uint32_t cpath = mix32(path * 0x9E3779B1u + 0x7FFFFFFFu);
                 qa_out[qslot + n_reflect] = make_float4(org.x, org.y, org.z, fd.x);
-                qb_out[qslot + n_reflect] = make_float4(fd.y, fd.z, i2f((int)cpath), i2f((int)mult));
+                qb_out[qslot + n_reflect] = make_float4(fd.y, fd.z, i2f((int)cpath), i2f((int)(mult | (replicated ? 0x80000000u : 0u))));
                 if (STATS) { ++n_refr; n_refr_ref += mult; }
             }
             if (STATS) {

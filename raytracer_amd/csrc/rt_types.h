@@ -100,7 +100,9 @@ struct DevFrame {
 // filled from its start through its own counter (see ctr below):
 //   node index = node_off[level] + region * node_rcap[level] + order of allocation inside the region
 //   queue slot = region * link_rcap[level] + order of allocation inside the region
-// Secondary-ray queue entry: q_a = (origin xyz, dir.x)  q_b = (dir.y, dir.z, bits path id, bits multiplicity)
+// Secondary-ray queue entry: q_a = (origin xyz, dir.x)  q_b = (dir.y, dir.z, bits path id, bits multiplicity | replicated << 31)
+//   multiplicity = how many identical rays of the reference this one stands for (statistics); replicated = a reflection
+//   above this ray was traced gr_samples times for real, so reflections below it are traced once (see k_extend)
 // link[link_off[level] + queue slot] = node index hit by that ray of `level`, or -1
 struct DevWork {
     float4* q_a[2]; float4* q_b[2];

@@ -372,6 +372,53 @@ def test_graph_replay_equals_plain_launches():
     r.close()
 
 
+def test_recorded_frames_survive_reallocation_of_the_work_buffers():
+    """A deeper or wider frame re-allocates the work buffers; frame graphs recorded before hold the old addresses and
+    must be dropped: configuration A three times (recorded and replayed), then B (grows the buffers), then A again."""
+    cfg_a, _ = api.parse_args(["-grs", "1"])
+    cfg_b, _ = api.parse_args(["-rd", "4", "-gr", "-grs", "3", "-ss", "-sss", "4"])
+    ls = api.LoadedScene(cases.SCENES["glass"](), cfg_a)
+    r = api.Renderer(0); r.upload(ls)
+    want_a, _ = r.render(cfg_a)
+    r.close()
+    r = api.Renderer(0); r.upload(ls)                     # fresh context: its first frames size the buffers for A only
+    out = torch.zeros(r.out_bytes(), dtype=torch.uint8, device="cuda")
+    out_b = torch.zeros_like(out)
+    for _ in range(3):
+        out.zero_(); r.render_device(cfg_a, out.data_ptr()); r.synchronize()
+        assert np.array_equal(out.cpu().numpy().reshape(want_a.shape), want_a)
+    r.render_device(cfg_b, out_b.data_ptr()); r.synchronize()
+    assert int(out_b.max()) > 0
+    filler = [torch.full((1 << 22,), 255, dtype=torch.uint8, device="cuda") for _ in range(8)]   # may land where the old buffers were
+    for _ in range(3):
+        out.zero_(); r.render_device(cfg_a, out.data_ptr()); r.synchronize()
+        assert np.array_equal(out.cpu().numpy().reshape(want_a.shape), want_a)
+    assert all(int(t.min()) == 255 for t in filler)
+    r.close(); ls.close()
+
+
+def test_rank_without_tiles_renders_an_empty_block():
+    """More ranks than tiles (a 64x32 film has two): the ranks that own nothing return a zeroed block, and the assembled
+    image is the unsharded one."""
+    text = cases.reference_scene(64, 32)
+    cfg, _ = api.parse_args(["-r", "-grs", "1"])
+    ls = api.LoadedScene(text, cfg)
+    whole = api.Renderer(0); whole.upload(ls)
+    full, _ = whole.render(cfg); whole.close()
+    blocks = []
+    for rank in range(8):
+        r = api.Renderer(0); r.upload(ls); r.set_shard(rank, 8)
+        out = torch.full((r.out_bytes(),), 9, dtype=torch.uint8, device="cuda")
+        st = r.render_device(cfg, out.data_ptr(), want_stats=True)
+        if r.local_tiles == 0:
+            assert st.total_rays() == 0 and int(out.max()) == 0
+            blk, _ = r.render(cfg)
+            assert blk.max() == 0
+        blocks.append(out.cpu().numpy()); r.close()
+    assert full.max() > 0 and np.array_equal(api.assemble_tiles_numpy(blocks, 64, 32), full)
+    ls.close()
+
+
 def test_shadow_overlap_equals_serial_launches():
     """Without statistics the shadow rays of the primary hits run on a second stream beside the deeper levels'
     tracing; with many batches per frame (small workspace, several samples) the forked frames must equal the
