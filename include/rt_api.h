@@ -230,6 +230,20 @@ int32_t rt_max_tiles_per_rank(const rt_ctx* ctx);
 int rt_render(rt_ctx* ctx, const rt_config* cfg, uint8_t* rgb_out, rt_stats* stats);
 int rt_render_device(rt_ctx* ctx, const rt_config* cfg, void* rgb_out_dev, rt_stats* stats);
 
+/* rt_render_device without statistics for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same inputs, same output
+ * layout and the same kernels as rt_render_device, but every work buffer of the frame (ray queues, hit tree, shadow
+ * counts, per-pixel sums, counters) is carved from one array that the library keeps in each GPU's memory for the life
+ * of the process (rt_noalloc_capacity() bytes, 64 MiB), and the call performs no hipMalloc / hipFree, creates no
+ * event and instantiates no graph: it only enqueues on the context's stream.  The film is rendered in as many batches
+ * as that array allows; RT_ERR_CAPACITY when it cannot hold the film's per-pixel sums plus one wavefront of samples
+ * (at most about 3.9 million pixel slots of 16 bytes).  All contexts of one GPU share the array and its previous
+ * contents are overwritten: calls that overlap on one GPU (two contexts, two streams) race; wait for one frame
+ * (rt_synchronize) before the next call on that GPU starts.  The scene must have been uploaded before (the uploads
+ * do allocate). */
+int rt_render_device_noalloc(rt_ctx* ctx, const rt_config* cfg, void* rgb_out_dev);
+uint64_t rt_noalloc_capacity(void);
+
 /* Rank 0 after the gather: tiles_dev = world * rt_max_tiles_per_rank()*32*32*3 bytes (rank-major, each block
  * as rt_render_device wrote it); rgb_out_dev = res_y*res_x*3 bytes row-major.  Enqueue only. */
 int rt_assemble_tiles(rt_ctx* ctx, const void* tiles_dev, int32_t world, void* rgb_out_dev);

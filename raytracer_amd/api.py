@@ -112,7 +112,7 @@ class HostBvh(C.Structure):
 # every symbol the two headers declare
 API_SYMBOLS = ["rt_default_config", "rt_create", "rt_destroy", "rt_set_stream", "rt_get_stream", "rt_set_option", "rt_upload_scene", "rt_upload_bvh",
                "rt_set_shard", "rt_local_tiles", "rt_max_tiles_per_rank", "rt_render", "rt_render_device",
-               "rt_assemble_tiles", "rt_synchronize", "rt_last_error"]
+               "rt_assemble_tiles", "rt_synchronize", "rt_last_error", "rt_render_device_noalloc", "rt_noalloc_capacity"]
 HOST_SYMBOLS = ["rt_host_parse_args", "rt_host_parse_scene", "rt_host_load_scene", "rt_host_free_scene",
                 "rt_host_build_bvh", "rt_host_free_bvh", "rt_host_read_ppm", "rt_host_write_ppm", "rt_host_write_ppm_binary", "rt_host_free",
                 "rt_host_camera_ray"]
@@ -142,6 +142,8 @@ def lib():
     L.rt_render.argtypes = [C.c_void_p, C.POINTER(Config), C.c_void_p, C.POINTER(Stats)]
     L.rt_render_device.argtypes = [C.c_void_p, C.POINTER(Config), C.c_void_p, C.POINTER(Stats)]
     L.rt_assemble_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.rt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(Config), C.c_void_p]
+    L.rt_noalloc_capacity.argtypes = []; L.rt_noalloc_capacity.restype = C.c_uint64
     L.rt_synchronize.argtypes = [C.c_void_p]
     L.rt_last_error.argtypes = [C.c_void_p]; L.rt_last_error.restype = C.c_char_p
     L.rt_host_parse_args.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(Config), C.c_char_p, C.c_int]
@@ -484,6 +486,10 @@ class Renderer:
         st = Stats() if want_stats else None
         self._check(lib().rt_render_device(self._ctx, C.byref(cfg), C.c_void_p(out_ptr), C.byref(st) if st else None))
         return st
+
+    def render_device_noalloc(self, cfg: Config, out_ptr: int):
+        """rt_render_device_noalloc: work buffers from the library's per-GPU scratch array, nothing allocated."""
+        self._check(lib().rt_render_device_noalloc(self._ctx, C.byref(cfg), C.c_void_p(out_ptr)))
 
     def assemble(self, tiles_ptr: int, world: int, out_ptr: int):
         self._check(lib().rt_assemble_tiles(self._ctx, C.c_void_p(tiles_ptr), world, C.c_void_p(out_ptr)))

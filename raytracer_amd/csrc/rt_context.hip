@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <limits>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -274,6 +275,8 @@ struct rt_ctx {
 #define RT_TRY(expr) do { int rc__ = (expr); if (rc__ != RT_OK) return rc__; } while (0)
 #define RT_HIP(ctx, call) RT_TRY((ctx)->hip((call), #call))
 
+static hipError_t lookup_scratch(int device);
+
 extern "C" {
 
 rt_ctx* rt_create(int device_id, uint64_t workspace_bytes) {
@@ -283,6 +286,9 @@ rt_ctx* rt_create(int device_id, uint64_t workspace_bytes) {
     if (device_id < 0 || device_id >= n) { g_create_error = "device id out of range"; return nullptr; }
     e = hipSetDevice(device_id);
     if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
+    // once per device, with that device current: where this GPU keeps the library's scratch array
+    e = lookup_scratch(device_id);
+    if (e != hipSuccess) { g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e); return nullptr; }
     rt_ctx* c = new rt_ctx();
     c->device = device_id;
     c->workspace_limit = workspace_bytes ? workspace_bytes : (4ull << 30);
@@ -948,8 +954,36 @@ static int make_plan(rt_ctx* c, const rt_config* cfg, int D, int L, bool texture
     return c->fail(RT_ERR_CAPACITY, "no batch size fits a work area of %llu bytes", budget);
 }
 
+// ---- one entry point that allocates nothing -----------------------------------------------------------------------
+// rt_render_device_noalloc takes every work buffer of a frame (ray queues, hit tree, links, shadow counts, pixel sums,
+// counters) from this array instead of hipMalloc'd memory.  One copy per GPU, held until the process ends.  The name
+// is only a host-side handle: device code must be given the address hipGetSymbolAddress returns for the current
+// device, which rt_create looks up once per device.
+#define RT_NOALLOC_BYTES (64ull << 20)
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
+enum { RT_MAX_DEVICES = 64 };
+static unsigned char* g_scratch_ptr[RT_MAX_DEVICES];       // per device: address of that GPU's copy of `scratch`
+static std::atomic<int> g_scratch_state[RT_MAX_DEVICES];   // 0 = not looked up, 1 = ready, -1 = lookup failed
+
+// device must be current
+static hipError_t lookup_scratch(int device) {
+    if (device < 0 || device >= RT_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (g_scratch_state[device].load() == 1) return hipSuccess;
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if (g_scratch_state[device].load() == 1) return hipSuccess;
+    void* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) { g_scratch_state[device] = -1; return e != hipSuccess ? e : hipErrorInvalidSymbol; }
+    g_scratch_ptr[device] = (unsigned char*)ptr;
+    g_scratch_state[device] = 1;
+    return hipSuccess;
+}
+
 // Enqueue one frame.  out_dev: device buffer in the layout rt_render_device documents.
-static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev, bool want_stats_zero, StageTimer* tm, bool count_stats = true) {
+// noalloc: the work buffers come from this GPU's `scratch` (through its looked-up address) and nothing is allocated.
+static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev, bool want_stats_zero, StageTimer* tm, bool count_stats = true,
+                         bool noalloc = false) {
     if (!c->have_scene) return c->fail(RT_ERR_STATE, "render before rt_upload_scene");
     if (cfg->bvh && !c->have_bvh) return c->fail(RT_ERR_STATE, "config asks for the BVH but none was uploaded");
     const int AA = cfg->anti_aliasing ? cfg->aa_samples : 1;
@@ -985,14 +1019,27 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         RT_HIP(c, hipSetDevice(c->device));
         const size_t pad = c->world > 1 ? (size_t)c->max_tiles * RT_TILE_PIX * 3 : (size_t)f.width * (size_t)f.height * 3;
         if (pad) RT_HIP(c, hipMemsetAsync(out_dev, 0, pad, c->stream));
-        if (want_stats_zero) { RT_HIP(c, c->stats.resize(RT_S_TOTAL)); RT_HIP(c, hipMemsetAsync(c->stats.p, 0, RT_S_TOTAL * sizeof(unsigned long long), c->stream)); }
+        if (want_stats_zero && !noalloc) { RT_HIP(c, c->stats.resize(RT_S_TOTAL)); RT_HIP(c, hipMemsetAsync(c->stats.p, 0, RT_S_TOTAL * sizeof(unsigned long long), c->stream)); }
         c->err.clear(); c->last_batches = 0;
         return RT_OK;
     }
     hipStream_t s = c->stream;
     RT_HIP(c, hipSetDevice(c->device));
 
-    const unsigned long long budget = c->workspace_limit;
+    // Fixed part of the work area (pixel sums, counters, statistics) and the budget left for the per-batch buffers
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t fixed_bytes = al((size_t)n_slots * sizeof(float4)) + al(RT_C_TOTAL * sizeof(int)) + al(RT_S_TOTAL * sizeof(unsigned long long));
+    unsigned long long budget = c->workspace_limit;
+    unsigned char* arena = nullptr;
+    if (noalloc) {
+        if (lookup_scratch(c->device) != hipSuccess) return c->fail(RT_ERR_HIP, "the library's scratch array has no address on device %d", c->device);
+        arena = g_scratch_ptr[c->device];
+        if (fixed_bytes + (1u << 20) > RT_NOALLOC_BYTES)
+            return c->fail(RT_ERR_CAPACITY, "rt_render_device_noalloc: a film of %lld pixel slots needs %zu bytes of pixel sums; the scratch array holds %llu bytes "
+                                            "(at most %llu pixel slots)", n_slots, fixed_bytes, (unsigned long long)RT_NOALLOC_BYTES,
+                           (unsigned long long)((RT_NOALLOC_BYTES - (2u << 20)) / sizeof(float4)));
+        budget = RT_NOALLOC_BYTES - fixed_bytes;
+    }
     WorkPlan plan;
     RT_TRY(make_plan(c, cfg, D, L, f.textures != 0, n_slots, budget, plan));
     const long long B = plan.B;
@@ -1002,7 +1049,22 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     const long long* node_off = plan.node_off; const long long* link_off = plan.link_off; const long long* rcap = plan.rcap;
 
     DevWork w; std::memset(&w, 0, sizeof w);
-    {
+    if (noalloc) {
+        // carve the scratch block: fixed part first, then the batch buffers (sizes as in plan_bytes)
+        unsigned char* q = arena;
+        auto take = [&](size_t bytes) { unsigned char* r = q; q += al(bytes); return r; };
+        w.accum = (float4*)take((size_t)n_slots * sizeof(float4));
+        w.ctr = (int*)take(RT_C_TOTAL * sizeof(int));
+        w.stats = (unsigned long long*)take(RT_S_TOTAL * sizeof(unsigned long long));
+        for (int k = 0; k < 2; ++k) { w.q_a[k] = (float4*)take(cap_rays * 16); w.q_b[k] = (float4*)take(cap_rays * 16); }
+        w.n_a = (float4*)take(cap_nodes * 16); w.n_b = (float4*)take(cap_nodes * 16); w.n_c = (float4*)take(cap_nodes * 16);
+        w.n_col = (float4*)take(cap_nodes * 16);
+        if (f.textures) w.n_uv = (float2*)take(cap_nodes * 8);
+        w.n_pix = (int*)take(cap_pix * 4);
+        w.shadow = (float*)take(plan.cap_shadow * 4);
+        w.link = (int*)take(cap_links * 4);
+        if ((size_t)(q - arena) > RT_NOALLOC_BYTES) return c->fail(RT_ERR_CAPACITY, "rt_render_device_noalloc: work plan exceeds the scratch array");
+    } else {
         const bool grow = cap_nodes > c->n_a.n || cap_links > c->link.n || cap_rays > c->q_a[0].n || (size_t)n_slots > c->accum.n ||
                           (f.textures && cap_nodes > c->n_uv.n) || plan.cap_shadow > c->shadow.n || cap_pix > c->n_pix.n;
         if (grow) {
@@ -1184,6 +1246,14 @@ int rt_render_device(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev, rt_stat
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return finish_stats(c, stats, ms, &tm);
 }
+
+int rt_render_device_noalloc(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev) {
+    if (!c || !cfg || !rgb_out_dev) return RT_ERR_ARG;
+    // plain launches (instantiating a frame graph allocates), no statistics (the event pool may have to grow)
+    return enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, false, nullptr, false, true);
+}
+
+uint64_t rt_noalloc_capacity(void) { return RT_NOALLOC_BYTES; }
 
 int rt_render(rt_ctx* c, const rt_config* cfg, uint8_t* rgb_out, rt_stats* stats) {
     if (!c || !cfg || !rgb_out) return RT_ERR_ARG;
