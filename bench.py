@@ -7,6 +7,9 @@ soft shadows): the configuration the headline metric is quoted on.  Scene, BVH a
 the timed region (they are broadcast once per frame set); with N > 1 every rank renders its interleaved 32x32
 tiles and the tile blocks are gathered to rank 0 over RCCL inside the timed region.
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (as a child
+`python -m torch.distributed.run`, before this process has touched a GPU) and relays rank 0's line.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -14,20 +17,14 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-
-import numpy as np
-import torch
-import torch.distributed as dist
-
-import cases
-from raytracer_amd import api
-from raytracer_amd import dist as rdist
 
 WORKLOADS = {
     # the headline configuration: reflection/refraction depth 4 + 16-sample soft shadows (soft shadows are -ss, config.cpp:15)
@@ -42,9 +39,16 @@ WORKLOADS = {
     # the reference's motion-blur scene with the multi-sample flag set at 1080p (64 samples per pixel)
     "cube_mb": dict(scene="blend:cube_mb", res=(1920, 1080), flags=["-aa", "-aas", "4", "-dof", "-dofs", "4", "-m", "-mbs", "4", "-r", "-gr", "-grs", "4"]),
     "config4": dict(scene="ref", res=(3840, 2160), flags=["-aa", "-aas", "16", "-gr", "-grs", "16", "-dof", "-dofs", "16", "-m", "-mbs", "16"]),
+    # the 4K multi-sample configuration at 64 instead of 4096 samples per pixel: the frame the multi-GPU split is meant for
+    "config4s": dict(scene="ref", res=(3840, 2160), flags=["-aa", "-aas", "4", "-gr", "-grs", "16", "-dof", "-dofs", "4", "-m", "-mbs", "4"]),
+    # the all-effects configuration, synthetic part: 10M random primitives (seed 43), 4K, every effect on at a reduced sample count
+    "config5s": dict(scene="random", n=10_000_000, seed=43, res=(3840, 2160),
+                     flags=["-aa", "-aas", "2", "-dof", "-dofs", "2", "-m", "-mbs", "2", "-t", "-ss", "-sss", "16", "-r", "-rd", "2", "-gr", "-grs", "4"]),
 }
 HBM_PEAK_GBS = 8000.0
-
+# FP32 vector peak of the chip: 1024 SIMDs x one 64-lane instruction per 2 cycles x 2.4 GHz x 2 flop (an FMA) per lane
+VALU_PEAK_TFLOPS = 157.3
+FLOP_PER_VALU_INST = 128.0
 
 # Algorithmic bytes per unit of work: what a wavefront pipeline with explicit ray and hit
 # records has to move per ray, independent of how this implementation lays the records out.
@@ -53,7 +57,168 @@ BYTES_PER_SHADOW_RAY = 72       # shadow-ray record 32 B written + read, result 
 BYTES_PER_SHADED_HIT = 32 + 64 + 48   # hit-tree node 16 B written + read, one primitive record, one material
 
 
-def copy_ceiling_GBps(dev) -> float:
+def describe(name: str) -> str:
+    wl = WORKLOADS[name]
+    what = "scene.json" if wl["scene"] == "ref" else wl["scene"][6:] if wl["scene"].startswith("blend:") else f"{wl['n']} random primitives"
+    return f"{name}: {what} {wl['res'][0]}x{wl['res'][1]}, flags {' '.join(wl['flags']) or '(none)'}"
+
+
+# ---- CPU baseline (runs before this process makes any GPU call) -----------------------------------------------------
+
+def _oracle_band(job):
+    """Worker of the all-cores leg: the oracle port on one horizontal band of the sample film."""
+    text, flags, tex, win = job
+    import oracle
+    _, st = oracle.render(text, flags, tex, window=win)
+    return st.total_rays()
+
+
+def port_all_cores(text: str, flags: list, w: int, h: int, textures: str) -> dict:
+    """The oracle port on every host core of this GPU's share: the film cut into bands, one forked worker per core
+    (the port is scalar and keeps global state, so it scales by processes, not threads)."""
+    import multiprocessing as mp
+    cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1), os.cpu_count() or 1, 16))
+    bands = min(h, cores * 16)
+    jobs = [(text, flags, textures, (0, (h * b) // bands, w, (h * (b + 1)) // bands)) for b in range(bands)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        rays = sum(pool.map_async(_oracle_band, jobs, chunksize=1).get(timeout=240))
+    secs = time.perf_counter() - t0
+    return {"port_all_cores_value": rays / max(secs, 1e-9), "port_all_cores_seconds": secs, "port_all_cores": cores}
+
+
+def cpu_baseline(workload: dict) -> dict:
+    """The reference's CPU path on a bounded sample of the same workload (same scene and flags, smaller film).
+    Must be called before torch.cuda / HIP is initialised in this process: it forks workers and runs a child."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import cases
+    import oracle
+    import ref_runner
+    from raytracer_amd import api
+    flags = workload["flags"]
+    if workload["scene"] == "random":
+        return {"unit": "rays/s", "value": None, "cores": 1, "kind": "port",
+                "sample": "not run: the reference needs minutes per thousand pixels on this scene (every leaf of its depth-8 tree "
+                          "holds thousands of primitives); its rate on its own scenes is in the default workload's line"}
+    textures = str(cases.TEXTURES)
+
+    def scene_at(w, h):
+        return cases.reference_scene(w, h) if workload["scene"] == "ref" else cases.blend_scene(workload["scene"][6:], w, h)
+
+    # Bounded sample: a pilot render of the port on a 96x54 film prices a pixel of this flag set (the reference re-traces
+    # its gr_samples identical reflection rays at every level, so deep recursion and high sample counts cost far more
+    # per pixel); the sample film is then sized for about 20 s of one core, at most 800x450.
+    _, pilot = oracle.render(scene_at(96, 54), flags, textures)
+    per_pixel = max(pilot.seconds, 1e-4) / (96 * 54)
+    # (the compiled reference is about five times slower per ray than the port: it allocates per vector operation)
+    budget_s = 4.0 if ref_runner.have_ref() else 15.0
+    pixels = min(800 * 450, max(48 * 27, int(budget_s / per_pixel)))
+    h = max(27, int((pixels * 9 / 16) ** 0.5)); w = h * 16 // 9
+    text = scene_at(w, h)
+    sample_flags = list(flags)
+    _, ost = oracle.render(text, sample_flags, textures)              # counts the rays the reference's code path traces
+    rays = ost.total_rays()
+    out = {"unit": "rays/s", "cores": 1,
+           "sample": f"{'scene.json' if workload['scene'] == 'ref' else workload['scene'][6:]} at {w}x{h} ({w*h} of "
+                     f"{workload['res'][0] * workload['res'][1]} pixels, same camera and flags: {' '.join(sample_flags) or '(none)'}), "
+                     f"{rays} rays, all counted as the reference traces them (it re-traces its gr_samples identical reflection rays per hit and level)"}
+    if ref_runner.have_ref():
+        tex = {p.name: p for p in cases.TEXTURES.glob("*.ppm")}
+        _, secs, _ = ref_runner.run_ref(text, sample_flags, tex)
+        out.update(kind="reference", value=rays / max(secs, 1e-9), seconds=secs, port_seconds=ost.seconds,
+                   port_value=rays / max(ost.seconds, 1e-9))
+    else:
+        out.update(kind="port", value=rays / max(ost.seconds, 1e-9), seconds=ost.seconds)
+    try:
+        out.update(port_all_cores(text, sample_flags, w, h, textures))
+    except Exception as e:                      # a reported extra, never a reason to lose the line
+        out["port_all_cores_error"] = repr(e)
+    return out
+
+
+# ---- launch ---------------------------------------------------------------------------------------------------------
+
+def self_launch(args) -> int:
+    """N > 1 without a torchrun environment: start the ranks as a child (this process has not touched a GPU and does
+    not exec: it waits and passes the child's exit status on)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def load_counters(workload: str) -> dict:
+    """Per-kernel, per-launch hardware counters of this workload collected by tools/profile.sh (rocprofv3 --pmc passes),
+    committed as profiles/counters_latest.json."""
+    f = ROOT / "profiles" / "counters_latest.json"
+    if not f.exists():
+        return {}
+    return json.loads(f.read_text()).get(workload, {}).get("kernels", {})
+
+
+def roofline(st, workload: str, small_scene: bool) -> dict:
+    """The dominant kernel (by device time in a profiled frame) against the limit that bounds it.  Launch durations
+    are measured live with HIP events on the render stream; instruction counts and HBM/L2 traffic per launch come from
+    the committed rocprofv3 counter passes of the same workload."""
+    kernels = {
+        "k_extend<true>": dict(units=st.primary_rays, bytes_per_unit=BYTES_PER_EXTEND_RAY, ms=st.ms_extend_primary, launches=st.launches_extend_primary),
+        "k_extend<false>": dict(units=st.reflection_rays + st.refraction_rays, bytes_per_unit=BYTES_PER_EXTEND_RAY,
+                                ms=st.ms_extend_secondary, launches=st.launches_extend_secondary),
+        "k_shadow": dict(units=st.shadow_rays, bytes_per_unit=BYTES_PER_SHADOW_RAY, ms=st.ms_shadow, launches=st.launches_shadow),
+        "k_shade": dict(units=st.nodes_shaded, bytes_per_unit=BYTES_PER_SHADED_HIT, ms=st.ms_shade, launches=st.launches_shade),
+    }
+    ctr = load_counters(workload)
+    for name, k in kernels.items():
+        n = max(1, k["launches"])
+        k["avg_launch_ms"] = k["ms"] / n
+        k["bytes_per_launch"] = k["units"] * k["bytes_per_unit"] / n
+        k["GBps"] = (k["units"] * k["bytes_per_unit"] / 1e9) / (k["ms"] / 1e3) if k["ms"] > 0 else 0.0
+        k["Grays_or_Ghits_per_s"] = (k["units"] / 1e9) / (k["ms"] / 1e3) if k["ms"] > 0 else 0.0
+        c = ctr.get(name)
+        if c and k["ms"] > 0:
+            secs = k["avg_launch_ms"] / 1e3
+            if c.get("SQ_INSTS_VALU"):
+                k["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
+                k["valu_TFLOPs_equiv"] = c["SQ_INSTS_VALU"] * FLOP_PER_VALU_INST / secs / 1e12
+                k["valu_issue_frac"] = k["valu_TFLOPs_equiv"] / VALU_PEAK_TFLOPS
+            if c.get("hbm_bytes_per_launch") is not None:
+                k["hbm_bytes_per_launch"] = c["hbm_bytes_per_launch"]
+                k["hbm_GBps"] = c["hbm_bytes_per_launch"] / 1e9 / secs
+            if c.get("TCC_HIT_sum") is not None and (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0:
+                k["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+            for extra in ("SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_INSTS_VMEM_RD"):
+                if c.get(extra):
+                    k[extra + "_per_launch"] = c[extra]
+    dom = max(kernels, key=lambda n: kernels[n]["ms"])
+    d = kernels[dom]
+    alg = {"achieved_GBps": d["GBps"], "peak_GBps": HBM_PEAK_GBS, "frac": d["GBps"] / HBM_PEAK_GBS, "bytes_per_launch": d["bytes_per_launch"],
+           "note": "prescribed per-ray record bytes x rays of the launch / launch duration; this implementation moves fewer bytes "
+                   "(primary rays are generated in registers, shadow rays are never stored)"}
+    traffic = d.get("hbm_bytes_per_launch")
+    out = {"kernel": dom, "avg_launch_ms": d["avg_launch_ms"], "traffic": traffic,
+           "traffic_ratio": (traffic / d["bytes_per_launch"]) if (traffic and d["bytes_per_launch"]) else None,
+           "hbm_algorithmic": alg, "l2_hit_rate": d.get("l2_hit_rate"), "by_kernel": kernels}
+    if small_scene and "valu_issue_frac" in d:
+        out.update(bound="valu", achieved=d["valu_TFLOPs_equiv"], peak=VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=d["valu_issue_frac"],
+                   note="a handful of primitives: nodes, primitive records and materials are served from LDS, HBM carries only the hit tree "
+                        "and the ray queues, and the kernels are bound by vector-instruction issue (IEEE divides, double-precision "
+                        "normalisation kept for bit parity).  achieved = vector instructions of the launch (rocprofv3 SQ_INSTS_VALU, "
+                        "committed counter pass) x 128 flop (64 lanes x one FMA) / launch duration measured live: the FP32 vector rate "
+                        "the used issue slots stand for; frac = share of the chip's vector issue slots in use")
+    elif not small_scene and d.get("hbm_GBps"):
+        out.update(bound="hbm", achieved=d["hbm_GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=d["hbm_GBps"] / HBM_PEAK_GBS,
+                   note="achieved = HBM bytes of the launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, committed counter pass) / launch duration "
+                        "measured live.  The walk of the second-level hierarchies is bound by the latency of dependent node and "
+                        "primitive fetches (L2 / Infinity Cache), not by streaming bandwidth; l2_hit_rate is from the same passes")
+    else:
+        out.update(bound="hbm", achieved=d["GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=d["GBps"] / HBM_PEAK_GBS,
+                   note="no committed counter pass for this workload: algorithmic record bytes / launch duration")
+    return out
+
+
+def copy_ceiling_GBps(torch, dev) -> float:
     """Device-to-device copy rate of this GPU (bytes read + written per second): the practical HBM ceiling next to
     the nominal 8 TB/s."""
     n = 1 << 30
@@ -67,122 +232,15 @@ def copy_ceiling_GBps(dev) -> float:
     return 5 * 2 * n / 1e9 / (e0.elapsed_time(e1) / 1e3)
 
 
-def roofline(st: api.Stats, workload: str, small_scene: bool) -> dict:
-    """Per-kernel achieved rate from the per-stage HIP-event times of one profiled frame."""
-    kernels = {
-        "k_extend<true>": dict(units=st.primary_rays, bytes_per_unit=BYTES_PER_EXTEND_RAY, ms=st.ms_extend_primary, launches=st.launches_extend_primary),
-        "k_extend<false>": dict(units=st.reflection_rays + st.refraction_rays, bytes_per_unit=BYTES_PER_EXTEND_RAY,
-                                ms=st.ms_extend_secondary, launches=st.launches_extend_secondary),
-        "k_shadow": dict(units=st.shadow_rays, bytes_per_unit=BYTES_PER_SHADOW_RAY, ms=st.ms_shadow, launches=st.launches_shadow),
-        "k_shade": dict(units=st.nodes_shaded, bytes_per_unit=BYTES_PER_SHADED_HIT, ms=st.ms_shade, launches=st.launches_shade),
-    }
-    for k in kernels.values():
-        k["avg_launch_ms"] = k["ms"] / max(1, k["launches"])
-        k["bytes_per_launch"] = k["units"] * k["bytes_per_unit"] / max(1, k["launches"])
-        k["GBps"] = (k["units"] * k["bytes_per_unit"] / 1e9) / (k["ms"] / 1e3) if k["ms"] > 0 else 0.0
-        k["Grays_or_Ghits_per_s"] = (k["units"] / 1e9) / (k["ms"] / 1e3) if k["ms"] > 0 else 0.0
-    dom = max(kernels, key=lambda n: kernels[n]["ms"])
-    d = kernels[dom]
-    traffic = None
-    tf = ROOT / "profiles" / "traffic_latest.json"
-    if tf.exists():                    # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile.sh)
-        t = json.loads(tf.read_text())
-        if t.get("workload") == workload and dom in t.get("kernels", {}):
-            traffic = t["kernels"][dom]["hbm_bytes_per_launch"]
-    return {"bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["GBps"] / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": dom, "avg_launch_ms": d["avg_launch_ms"], "bytes_per_launch": d["bytes_per_launch"],
-            "by_kernel": kernels,
-            "note": ("scene.json has 3 primitives: BVH nodes and primitive records are served from LDS/L2, HBM carries only the "
-                     "ray queues and the hit tree, and the kernels are bound by VALU work (IEEE divides, double-precision "
-                     "normalisation kept for bit parity), so the HBM fraction is small by construction") if small_scene else
-                    ("the algorithmic bytes count ray and hit records only; on this scene the time goes to the dependent "
-                     "node/primitive fetches of the second-level hierarchy walk (L2/HBM latency), not to streaming")}
+def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps: int, warmup: int, frames_in_flight: int, detail: bool) -> dict | None:
+    """Uploads the workload on every rank, times `steps` frames, returns rank 0's result dictionary."""
+    import torch
+    import torch.distributed as dist
+    import cases
+    from raytracer_amd import api
+    from raytracer_amd import dist as rdist
 
-
-def _oracle_band(job):
-    """Worker of the all-cores leg: the oracle port on one horizontal band of the sample film."""
-    text, flags, tex, win = job
-    import oracle
-    _, st = oracle.render(text, flags, tex, window=win)
-    return st.total_rays()
-
-
-def port_all_cores(text: str, flags: list, w: int, h: int) -> dict:
-    """The oracle port on every host core of this GPU's share: the film cut into bands, one forked worker per core
-    (the port is scalar and keeps global state, so it scales by processes, not threads)."""
-    import multiprocessing as mp
-    cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1), os.cpu_count() or 1, 16))
-    bands = min(h, cores * 16)
-    jobs = [(text, flags, str(cases.TEXTURES), (0, (h * b) // bands, w, (h * (b + 1)) // bands)) for b in range(bands)]
-    t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
-        rays = sum(pool.map(_oracle_band, jobs, chunksize=1))
-    secs = time.perf_counter() - t0
-    return {"port_all_cores_value": rays / max(secs, 1e-9), "port_all_cores_seconds": secs, "port_all_cores": cores}
-
-
-def cpu_baseline(workload: dict) -> dict:
-    """The reference's CPU path on a bounded sample of the same workload (same scene and flags, smaller film)."""
-    sys.path.insert(0, str(ROOT / "oracle"))
-    import oracle
-    import ref_runner
-    flags = workload["flags"]
-    if workload["scene"] == "random":
-        return {"unit": "rays/s", "value": None, "cores": 1, "kind": "port",
-                "sample": "not run: the reference needs minutes per thousand pixels on this scene (every leaf of its depth-8 tree "
-                          "holds thousands of primitives); its rate on its own scenes is in the default workload's line"}
-    cfg, _ = api.parse_args(flags)
-    spp = max(1, cfg.samples_per_pixel())
-    scale = max(1, int(round(spp ** 0.5)))                       # keep the sample near 360 000 primary samples
-    w, h = max(32, 800 // scale), max(18, 450 // scale)
-    text = cases.reference_scene(w, h) if workload["scene"] == "ref" else cases.blend_scene(workload["scene"][6:], w, h)
-    _, ost = oracle.render(text, flags, str(cases.TEXTURES))          # counts the rays the reference's code path traces
-    rays = ost.total_rays()
-    out = {"unit": "rays/s", "cores": 1,
-           "sample": f"{'scene.json' if workload['scene'] == 'ref' else workload['scene'][6:]} at {w}x{h} ({w*h} of {workload['res'][0] * workload['res'][1]} pixels, same camera and flags), flags {' '.join(flags)}, {rays} rays "
-                     f"(the reference re-traces its 16 identical reflection rays per hit; all are counted)"}
-    if ref_runner.have_ref():
-        tex = {p.name: p for p in cases.TEXTURES.glob("*.ppm")}
-        _, secs, _ = ref_runner.run_ref(text, flags, tex)
-        out.update(kind="reference", value=rays / max(secs, 1e-9), seconds=secs, port_seconds=ost.seconds,
-                   port_value=rays / max(ost.seconds, 1e-9))
-    else:
-        out.update(kind="port", value=rays / max(ost.seconds, 1e-9), seconds=ost.seconds)
-    try:
-        out.update(port_all_cores(text, flags, w, h))
-    except Exception as e:                      # a reported extra, never a reason to lose the line
-        out["port_all_cores_error"] = repr(e)
-    return out
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)        # a frame takes a fraction of a millisecond: time enough of them
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=4,
-                    help="contexts rendering consecutive frames concurrently on their own streams (1 = one frame at a time)")
-    ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
-    ap.add_argument("--single-device", action="store_true",
-                    help="rehearsal on a one-GPU machine: every rank uses GPU 0 (use with --backend gloo)")
-    args = ap.parse_args()
-
-    if args.single_device:
-        os.environ["LOCAL_RANK"] = "0"
-    rank, world, local = rdist.init_process_group(args.backend)
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
-    if not torch.cuda.is_available():
-        print("bench.py needs a GPU: the render path has no CPU fallback", file=sys.stderr)
-        sys.exit(2)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    wl = WORKLOADS[args.workload]
+    wl = WORKLOADS[name]
     W, H = wl["res"]
     # Rank 0 parses the scene and builds the BVH on its host; flags and the flat scene/BVH arrays are broadcast once
     # per frame set (over RCCL with the nccl backend), every rank uploads its copy.
@@ -190,6 +248,7 @@ def main():
     flags = json.loads(rdist.broadcast_bytes(json.dumps(wl["flags"]).encode() if rank == 0 else None, 0, on_dev).decode())
     cfg, _ = api.parse_args(flags)
     ls = None
+    t_load = time.perf_counter()
     if rank == 0:
         if wl["scene"] == "ref":
             ls = api.LoadedScene(cases.reference_scene(W, H), cfg, str(cases.TEXTURES))
@@ -197,15 +256,14 @@ def main():
             ls = api.LoadedScene(cases.blend_scene(wl["scene"][6:], W, H), cfg, str(cases.TEXTURES))
         else:
             from raytracer_amd import scenegen as sg
-            ls = api.ArrayScene(sg.random_prims(wl["n"], 42), (W, H))
+            ls = api.ArrayScene(sg.random_prims(wl["n"], wl.get("seed", 42), moving=bool(cfg.motion_blur)), (W, H), moving=bool(cfg.motion_blur))
     ls = rdist.broadcast_scene(ls, bool(cfg.bvh), 0, on_dev)
     # Frames in flight: consecutive frames are independent, so P contexts (each with its own work buffers and stream)
     # render them concurrently; a frame's small launches (deep recursion levels) then fill the other frames' gaps.
-    # Four by default: one per hardware queue of the process (more share queues and lose again).
-    # Not used for frames of many batches, which keep the GPU busy on their own.  With three or more frames in flight
-    # the contexts do not fork their shadow launches onto second streams: the frames already overlap each other, and
-    # a process has only four hardware queues for all of its streams.
-    P = max(1, args.frames_in_flight) if cfg.samples_per_pixel() <= 64 else 1
+    # Four by default: one per hardware queue of the process (more share queues and lose again).  Not used for frames
+    # of many samples per pixel, which keep the GPU busy on their own.
+    spp = cfg.samples_per_pixel()
+    P = max(1, frames_in_flight) if spp < 16 else 1
     if world > 1:
         P = min(P, 3)                                 # the communicator's stream takes the fourth hardware queue
 
@@ -220,6 +278,7 @@ def main():
     r = new_renderer()
     r.upload(ls, with_bvh=bool(cfg.bvh))
     r.set_shard(rank, world)
+    upload_s = time.perf_counter() - t_load
     # Everything of a step runs on the context's own stream, which torch sees as an external stream (the RCCL gather
     # is ordered against it).  No further streams are created for rendering: a process has few hardware queues, and
     # two render streams that share one do not overlap.
@@ -240,51 +299,50 @@ def main():
     staged = args.backend == "gloo"      # rehearsal path: gloo moves host tensors
 
     # N > 1 over RCCL: frames are pipelined.  Frame k is rendered on the render stream into one of two blocks; its
-    # gather runs on the communicator's stream and rank 0 re-orders it on a third stream, both beside the kernels of
-    # frame k + 1.  Buffers are reused every other frame behind events; the timed region ends with a device-wide
-    # synchronisation, so every frame's image has reached rank 0 inside it.
+    # gather runs on the communicator's stream and rank 0 re-orders it, both beside the kernels of frame k + 1.
+    # Buffers are reused every other frame behind events; the timed region ends with a device-wide synchronisation,
+    # so every frame's image has reached rank 0 inside it.
     pipelined = world > 1 and not staged
     # With several pipelines taking turns, rank 0 re-orders each frame on that frame's own render stream (no fifth stream)
     inline = P >= 2
     asm_stream = torch.cuda.Stream(dev) if (pipelined and rank == 0 and not inline) else None
     pipes = [rdist.FramePipeline(rr, cfg, rank, world, dev, ss, asm_stream=asm_stream, assemble_inline=inline) for rr, ss, _ in ctxs] if pipelined else None
     frame_no = [0]
+    keep = []
 
     def step():
         k = frame_no[0] % P; frame_no[0] += 1
         if pipelined:
             pipes[k].step()
-            return None
+            return
         if world == 1:
             rr, _, bb = ctxs[k]
             rr.render_device(cfg, bb.data_ptr())
-            return None
+            return
         r.render_device(cfg, block.data_ptr())
-        if world > 1:
-            g = rdist.gather_blocks(block.cpu(), 0)
-            gathered = g.to(dev) if rank == 0 else None
-            if rank == 0:
-                r.assemble(gathered.data_ptr(), world, image.data_ptr())
-                keep.append(gathered)            # the assemble kernel is only enqueued: keep its input alive
-                del keep[:-2]
-        return None
-
-    keep = []
+        g = rdist.gather_blocks(block.cpu(), 0)
+        if rank == 0:
+            gathered = g.to(dev)
+            r.assemble(gathered.data_ptr(), world, image.data_ptr())
+            keep.append(gathered)            # the assemble kernel is only enqueued: keep its input alive
+            del keep[:-2]
 
     # Ray counts (identical every frame: the generator is counter based) and per-kernel device times.  The profiled
     # frame is enqueued behind four ordinary ones so that the GPU, not the host, paces it.
     st = r.render_device(cfg, block.data_ptr(), want_stats=True)     # ray counts (the counting kernel variants)
-    r.set_option("skip_unlit", 0)                                    # how many shadow rays the N.L <= 0 rule leaves untraced
-    shadow_all = r.render_device(cfg, block.data_ptr(), want_stats=True).shadow_rays
-    r.set_option("skip_unlit", 1)
-    for _ in range(4):
-        r.render_device(cfg, block.data_ptr())
-    r.set_option("count_rays", 0)                                    # stage times with the kernels the timed frames run
-    tm = r.render_device(cfg, block.data_ptr(), want_stats=True)
-    r.set_option("count_rays", 1)
-    for name in ("ms_extend_primary", "ms_extend_secondary", "ms_shadow", "ms_shade", "ms_other", "ms_total",
-                 "launches_extend_primary", "launches_extend_secondary", "launches_shadow", "launches_shade"):
-        setattr(st, name, getattr(tm, name))
+    shadow_all = None
+    if detail:
+        r.set_option("skip_unlit", 0)                                # how many shadow rays the N.L <= 0 rule leaves untraced
+        shadow_all = r.render_device(cfg, block.data_ptr(), want_stats=True).shadow_rays
+        r.set_option("skip_unlit", 1)
+        for _ in range(4):
+            r.render_device(cfg, block.data_ptr())
+        r.set_option("count_rays", 0)                                # stage times with the kernels the timed frames run
+        tm = r.render_device(cfg, block.data_ptr(), want_stats=True)
+        r.set_option("count_rays", 1)
+        for field in ("ms_extend_primary", "ms_extend_secondary", "ms_shadow", "ms_shade", "ms_other", "ms_total",
+                      "launches_extend_primary", "launches_extend_secondary", "launches_shadow", "launches_shade"):
+            setattr(st, field, getattr(tm, field))
     rays_local = torch.tensor([st.primary_rays, st.shadow_rays, st.reflection_rays, st.refraction_rays,
                                st.shadow_rays_ref + st.reflection_rays_ref + st.refraction_rays_ref, st.nodes_shaded],
                               dtype=torch.float64, device=dev)
@@ -296,20 +354,22 @@ def main():
 
     # latency of one frame alone (enqueue -> done), next to the throughput the timed loop measures
     torch.cuda.synchronize(dev)
+    n_lat = 10 if spp < 16 else 2
+    r.render_device(cfg, block.data_ptr()); r.synchronize()
     t_lat = time.perf_counter()
-    for _ in range(10):
+    for _ in range(n_lat):
         r.render_device(cfg, block.data_ptr()); r.synchronize()
-    frame_latency_ms = (time.perf_counter() - t_lat) * 100.0
+    frame_latency_ms = (time.perf_counter() - t_lat) * 1000.0 / n_lat
     # every context records a frame graph on its second frame with the same output buffer; a pipeline alternates
     # between two blocks, so it needs four frames before both graphs exist
-    warm_steps = max(args.warmup, (4 if pipelined else 2) * P)
+    warm_steps = max(warmup, (4 if pipelined else 2) * P)
     for _ in range(warm_steps):
         step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     t_enq = time.perf_counter() - t0
     if world > 1:
@@ -321,42 +381,127 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    res = None
     if rank == 0:
-        ms_per_step = 1000.0 * elapsed / args.steps
         # rank-0 sanity: the frame is not black and (N=1) is the row-major image itself
         last = (frame_no[0] - 1) % P
         final = ((pipes[last].image if pipelined else image) if world > 1 else ctxs[last][2]).cpu().numpy()
         lit = float((final.reshape(-1, 3).sum(axis=1) > 0).mean())
+        res = {"workload": describe(name), "value": rays_total / (elapsed / steps), "ms_per_step": 1000.0 * elapsed / steps,
+               "steps": steps, "warmup": warm_steps, "spp": spp, "frames_in_flight": P, "frame_ms_alone": frame_latency_ms,
+               "host_enqueue_ms_per_step": 1000.0 * t_enq / steps, "upload_seconds": upload_s,
+               "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3],
+                                  "hits_shaded": tot[5], "as_the_reference_would_trace_them": tot[0] + tot[4],
+                                  "shadow_not_traced_because_the_surface_faces_away_from_the_light":
+                                      (shadow_all - st.shadow_rays) if (world == 1 and shadow_all is not None) else None},
+               "lit_fraction": lit, "stats": st}
+    torch.cuda.synchronize(dev)
+    torch.cuda.set_stream(torch.cuda.default_stream(dev))      # the contexts' streams die with them
+    for rr, _, _ in ctxs:
+        rr.close()
+    ls.close()
+    del pipes, ctxs, block, image, keep
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)        # a frame takes milliseconds: time enough of them
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scaling-4k", action="store_true", help="skip the second, 4K multi-sample measurement (scaling_4k)")
+    ap.add_argument("--frames-in-flight", type=int, default=4,
+                    help="contexts rendering consecutive frames concurrently on their own streams (1 = one frame at a time)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a one-GPU machine: every rank uses GPU 0 (use with --backend gloo)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start the ranks, initialise the process group, reduce one number, print it and stop (needs no GPU)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    from raytracer_amd import dist as rdist
+    rank, world, local = rdist.env_rank_world()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+
+    # The CPU leg first: it forks workers and runs the reference binary as a child, which must not happen in a process
+    # that has initialised the GPU runtime.
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.launch_check:
+        try:
+            cpu = cpu_baseline(WORKLOADS[args.workload])
+        except Exception as e:
+            cpu = {"unit": "rays/s", "value": None, "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+
+    import torch
+    import torch.distributed as dist
+    if args.single_device:
+        os.environ["LOCAL_RANK"] = "0"; local = 0
+    if args.launch_check:
+        rdist.init_process_group(args.backend or "gloo")
+        x = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(x); dist.barrier()
+        if rank == 0:
+            print(json.dumps({"launch_check": "ok", "world": world, "sum_of_ranks_plus_one": float(x.item())}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    rank, world, local = rdist.init_process_group(args.backend)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU: the render path has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    head = run_workload(args.workload, args, rank, world, local, dev, args.steps, args.warmup, args.frames_in_flight, detail=True)
+    big = None
+    if not args.no_scaling_4k and args.workload == "config2":
+        # the frame the tile split is designed for: 4K, 64 samples per pixel (config 2 alone is a sub-millisecond frame per shard)
+        big = run_workload("config4s", args, rank, world, local, dev, steps=max(3, min(10, args.steps)), warmup=2, frames_in_flight=1, detail=False)
+
+    if rank == 0:
+        wl = WORKLOADS[args.workload]
+        st = head.pop("stats")
         line = {
             "metric": "rays/sec (all ray types), 1080p scene.json" if args.workload == "config2" else f"rays/sec (all ray types), {args.workload}",
-            "value": rays_total / (elapsed / args.steps), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": warm_steps,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "value": head["value"], "unit": "rays/s", "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"],
+            "ms_per_step": head["ms_per_step"], "frame_ms_alone": head["frame_ms_alone"],
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic: the reference's own ASCII/scene.json (committed as a fixture), no dataset" if wl["scene"] == "ref"
                     else f"the reference's Blend/{wl['scene'][6:]}.blend exported to scene.json text (committed as a fixture)" if wl["scene"].startswith("blend:")
-                    else f"synthetic: {wl['n']} random spheres/cubes (seed 42) over a ground plane, generated in-process",
-            "config": {"workload": f"{args.workload}: {'scene.json' if wl['scene'] == 'ref' else wl['scene'][6:] if wl['scene'].startswith('blend:') else str(wl['n']) + ' random primitives'} {W}x{H}, flags {' '.join(wl['flags']) or '(none)'}",
-                       "spp": cfg.samples_per_pixel(), "tiles": "32x32 interleaved, rank = (tx+ty) % N",
-                       "frames_in_flight": P, "frame_ms_alone": frame_latency_ms, "host_enqueue_ms_per_step": 1000.0 * t_enq / args.steps,
+                    else f"synthetic: {wl['n']} random spheres/cubes (seed {wl.get('seed', 42)}) over a ground plane, generated in-process",
+            "config": {"workload": head["workload"], "spp": head["spp"], "tiles": "32x32 interleaved, rank = (tx+ty) % N",
+                       "frames_in_flight": head["frames_in_flight"], "frame_ms_alone": head["frame_ms_alone"],
+                       "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
                        "timing": "ms_per_step = timed wall clock / steps with frames_in_flight independent frames overlapping on the GPU; "
                                  "frame_ms_alone = one frame enqueued and waited for by itself",
-                       "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3],
-                                          "hits_shaded": tot[5], "as_the_reference_would_trace_them": tot[0] + tot[4],
-                                          "shadow_not_traced_because_the_surface_faces_away_from_the_light": (shadow_all - st.shadow_rays) if world == 1 else None},
-                       "lit_fraction": lit},
+                       "soft_shadow_sampling": "the first reflection of every path is traced gr_samples times (each copy draws its own "
+                                               "shadow samples, as the reference's identical rays do); deeper reflections are traced once",
+                       "rays_per_frame": head["rays_per_frame"], "lit_fraction": head["lit_fraction"]},
             "roofline": roofline(st, args.workload, wl["scene"] != "random"),
         }
-        ceiling = copy_ceiling_GBps(dev)
+        ceiling = copy_ceiling_GBps(torch, dev)
         line["roofline"]["measured_copy_GBps"] = ceiling
-        line["roofline"]["frac_of_measured_copy"] = line["roofline"]["achieved"] / ceiling
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(wl)
+        if big is not None:
+            big.pop("stats")
+            line["scaling_4k"] = {"metric": "rays/sec (all ray types), 4K multi-sample frame", "unit": "rays/s", "n_gpus": world,
+                                  **{k: big[k] for k in ("workload", "value", "ms_per_step", "steps", "warmup", "spp", "frames_in_flight", "frame_ms_alone", "rays_per_frame")}}
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    for rr, _, _ in ctxs:
-        rr.close()
-    ls.close()
 
 
 if __name__ == "__main__":

@@ -205,7 +205,11 @@ void* rt_get_stream(rt_ctx* ctx);
  * 0 = chosen per launch (default).  The one switch that does move rendered values, and only those
  * of soft-shadow renders, within their sampling noise: "fast_samples" = 0/1, whether the randomly drawn soft-shadow
  * sample rays are tested with hardware reciprocals (1 ulp) instead of IEEE division; default 1, 0 = the reference's
- * arithmetic.  Deterministic renders never use it. */
+ * arithmetic.  Deterministic renders never use it.  "replicate_reflections" = 0/1 (soft-shadow renders without -gr only):
+ * the reference traces gr_samples identical reflection rays per hit and each of their hits draws its own shadow samples
+ * (raytracer.cpp:400-432 over :330-332); 1 (default) traces the first reflection of every path gr_samples times so that
+ * a reflected penumbra has the reference's distribution, 0 traces it once and re-uses the colour (same mean, gr_samples
+ * times the variance in reflected penumbrae, far fewer rays). */
 int rt_set_option(rt_ctx* ctx, const char* name, int64_t value);
 
 /* Copies the scene to the device (replaces raytracer.cpp:55-59 as the producer of the render loop's inputs). */

@@ -26,12 +26,19 @@ import numpy as np
 
 HERE = Path(__file__).resolve().parent
 REF_BIN = HERE / "_ref" / "raytracer_ref"
+# the reference's own front end (parsers, BVHNode::buildBVH, Image) bound to the HIP library in place of its pixel loop
+# (oracle/ref_bind.cpp, `make -C oracle bind`); needs a GPU to run
+BIND_BIN = HERE / "_ref" / "ref_bind"
 
 _RES_RE = re.compile(r'("film_resolution"\s*:\s*\{\s*"width"\s*:\s*)([0-9.]+)(\s*,\s*"height"\s*:\s*)([0-9.]+)')
 
 
 def have_ref() -> bool:
     return REF_BIN.exists() and os.access(REF_BIN, os.X_OK)
+
+
+def have_bind() -> bool:
+    return BIND_BIN.exists() and os.access(BIND_BIN, os.X_OK)
 
 
 def set_resolution(scene_text: str, width: int, height: int) -> str:
@@ -67,10 +74,12 @@ def parse_p3(path: Path) -> np.ndarray:
 
 
 def run_ref(scene_text: str, flags: list[str], textures: dict[str, Path] | None = None,
-            timeout: float = 3600.0, keep_dir: str | None = None):
-    """Render scene_text with the reference binary. Returns (image int32 [H,W,3], loop_seconds, stdout)."""
-    if not have_ref():
-        raise FileNotFoundError(f"{REF_BIN} not built (make -C oracle ref)")
+            timeout: float = 3600.0, keep_dir: str | None = None, exe: Path | None = None):
+    """Render scene_text with the reference binary (or another executable that keeps its file layout, `exe`).
+    Returns (image int32 [H,W,3], loop_seconds, stdout)."""
+    exe = Path(exe) if exe else REF_BIN
+    if not (exe.exists() and os.access(exe, os.X_OK)):
+        raise FileNotFoundError(f"{exe} not built (make -C oracle ref / bind)")
     w, h = get_resolution(scene_text)
     root = Path(keep_dir) if keep_dir else Path(tempfile.mkdtemp(prefix="rtref_"))
     try:
@@ -81,7 +90,7 @@ def run_ref(scene_text: str, flags: list[str], textures: dict[str, Path] | None 
         for name, src in (textures or {}).items():
             shutil.copyfile(src, root / "Textures" / name)
         t0 = time.time()
-        p = subprocess.run([str(REF_BIN), *flags, "-o", "out.ppm"], cwd=root / "Code",
+        p = subprocess.run([str(exe), *flags, "-o", "out.ppm"], cwd=root / "Code",
                            capture_output=True, text=True, timeout=timeout)
         wall = time.time() - t0
         if p.returncode != 0:

@@ -6,10 +6,11 @@
 
 // One group of primitives that gets a hierarchy: class-wise ranges in a primitive set, and where its items,
 // entries and nodes go.  A group of n items becomes a perfect binary tree with 2^depth runs of 2..RT_SUB_LEAF
-// entries (depth = ceil(log2(ceil(n / RT_SUB_LEAF))) >= 1), i.e. 2^depth - 1 nodes starting at node_base.
+// entries (depth = ceil(log2(ceil(n / RT_SUB_LEAF))) >= 1): 2^depth - 1 nodes in heap order starting at node_base, for
+// which 2^depth node slots are reserved, and four entry slots per run starting at 4 * node_base.
 struct BuildGroup {
     int p0, pn, c0, cn, s0, sn;
-    int item_base;     // first item of the group = first entry of the group, relative to the build's entry_base
+    int item_base;     // first item of the group in the build's item arrays
     int node_base;     // absolute index of the group's root in the node array
     int n, depth;
 };
@@ -25,10 +26,10 @@ hipError_t rt_build_scene_bounds(hipStream_t s, const DevPrimSet& set, float out
 
 // Builds the hierarchies of `groups` (host array, items numbered group after group) over `set`.
 // sphere_e = squared-distance rounding allowance of the sphere test; nodes / entries = device arrays (absolute node
-// indices; entries start at entry_base).  When final6 != NULL it receives the union of the (enlarged) item boxes.
+// indices; a group's entries start at 4 * node_base).  When final6 != NULL it receives the union of the (enlarged) item boxes.
 // Synchronises the stream.
 hipError_t rt_build_hierarchies(hipStream_t s, const DevPrimSet& set, const BuildGroup* groups, int n_groups, long long n_items,
-                                double sphere_e, float4* nodes, int* entries, long long entry_base, float final6[6]);
+                                double sphere_e, float4* nodes, int* entries, float final6[6]);
 
 // Leaf-order copies of the file-order primitive records.  leaf_desc (host): per leaf (first id in prim_ids, planes,
 // cubes, spheres) and (first leaf-order plane, cube, sphere, 0).  prim_ids_dev holds validated indices.

@@ -6,7 +6,9 @@
 //   1. one lane per primitive: true bounds (everything the primitive can occupy for ray times in [0,1], enlarged for
 //      rounding and for what the reference's float sphere test reports outside the geometry);
 //   2. every group becomes a perfect binary tree over an ordering of its items: node j of level l owns the items at
-//      positions [j*n >> l, (j+1)*n >> l), the 2^depth runs at the bottom hold 2..4 items.  The ordering is made level
+//      positions [j*n >> l, (j+1)*n >> l), the 2^depth runs at the bottom hold 1..4 items.  Nodes are stored in heap
+//      order from the group's node_base (2^depth slots are reserved, one stays unused), run j's entries in the four
+//      slots from 4 * (node_base + j): the traversal computes both addresses from a node's index alone.  The ordering is made level
 //      by level, top down: the centres of each node's items are bounded (atomics per node), and one radix sort over
 //      all items of all groups (rocPRIM; key = node << 32 | centre along the node's widest axis) puts the lower half
 //      of every node first - a median split of every node of the level at once;
@@ -231,10 +233,18 @@ __global__ __launch_bounds__(256) void k_node_keys(const BuildGroup* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_entries(const float4* __restrict__ boxes, const unsigned* __restrict__ sorted, long long n,
-                                                 int* __restrict__ entries) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        entries[i] = f2i(boxes[2 * (size_t)sorted[i]].w);
+// Run j of a group owns the entry slots 4 * (node_base + j) .. + 3: its 2..4 sorted items, then -1.
+__global__ __launch_bounds__(256) void k_entries(const BuildGroup* __restrict__ groups, const float4* __restrict__ boxes,
+                                                 const unsigned* __restrict__ sorted, int* __restrict__ entries) {
+    const BuildGroup g = groups[blockIdx.y];
+    const long long runs = 1ll << g.depth;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < runs; j += (long long)gridDim.x * blockDim.x) {
+        const long long a = (j * (long long)g.n) >> g.depth, b = ((j + 1) * (long long)g.n) >> g.depth;
+        int4 e = make_int4(-1, -1, -1, -1);
+        int* ev = &e.x;
+        for (long long p = a; p < b && p < a + RT_SUB_LEAF; ++p) ev[p - a] = f2i(boxes[2 * (size_t)sorted[(size_t)g.item_base + (size_t)p]].w);
+        *(int4*)(entries + 4 * ((size_t)g.node_base + (size_t)j)) = e;
+    }
 }
 
 DEVI void box_union(float4& mn, float4& mx, float4 a, float4 b) {
@@ -244,7 +254,7 @@ DEVI void box_union(float4& mn, float4& mx, float4 a, float4 b) {
 
 // Lowest interior level: node = parent of two runs of sorted items.
 __global__ __launch_bounds__(256) void k_leaf_parents(const BuildGroup* __restrict__ groups, const float4* __restrict__ boxes,
-                                                      const unsigned* __restrict__ sorted, long long entry_base, float4* __restrict__ nodes) {
+                                                      const unsigned* __restrict__ sorted, float4* __restrict__ nodes) {
     const BuildGroup g = groups[blockIdx.y];
     const long long half = 1ll << (g.depth - 1);
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < half; t += (long long)gridDim.x * blockDim.x) {
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(256) void k_leaf_parents(const BuildGroup* __restri
                 const size_t item = sorted[(size_t)g.item_base + (size_t)p];
                 box_union(mn, mx, boxes[2 * item], boxes[2 * item + 1]);
             }
-            mn.w = i2f(~(int)(entry_base + g.item_base + a));
+            mn.w = i2f(~(int)(4 * ((long long)g.node_base + j)));
             mx.w = i2f((int)(b - a));
             out[2 * side] = mn; out[2 * side + 1] = mx;
         }
@@ -348,7 +358,7 @@ hipError_t rt_build_scene_bounds(hipStream_t s, const DevPrimSet& set, float out
 }
 
 hipError_t rt_build_hierarchies(hipStream_t s, const DevPrimSet& set, const BuildGroup* groups, int n_groups, long long n_items,
-                                double sphere_e, float4* nodes, int* entries, long long entry_base, float final6[6]) {
+                                double sphere_e, float4* nodes, int* entries, float final6[6]) {
     if (final6) for (int i = 0; i < 3; ++i) { final6[i] = INFINITY; final6[3 + i] = -INFINITY; }
     if (n_groups <= 0 || n_items <= 0) return hipSuccess;
     if (n_groups > 65535 || n_items > 0x7fffffffll) return hipErrorInvalidValue;
@@ -395,8 +405,8 @@ hipError_t rt_build_hierarchies(hipStream_t s, const DevPrimSet& set, const Buil
         unsigned* t = d_ord; d_ord = d_ord2; d_ord2 = t;
     }
 
-    hipLaunchKernelGGL(k_entries, dim3(grid_for(n_items)), dim3(256), 0, s, d_boxes, d_ord, n_items, entries + entry_base);
-    hipLaunchKernelGGL(k_leaf_parents, dim3(grid_for(((long long)max_n + 3) / 4), n_groups), dim3(256), 0, s, d_groups, d_boxes, d_ord, entry_base, nodes);
+    hipLaunchKernelGGL(k_entries, dim3(grid_for(1ll << max_depth), n_groups), dim3(256), 0, s, d_groups, d_boxes, d_ord, entries);
+    hipLaunchKernelGGL(k_leaf_parents, dim3(grid_for(((long long)max_n + 3) / 4), n_groups), dim3(256), 0, s, d_groups, d_boxes, d_ord, nodes);
     for (int h = 2; h <= max_depth; ++h)
         hipLaunchKernelGGL(k_upper_level, dim3(grid_for(1ll << (max_depth - h)), n_groups), dim3(256), 0, s, d_groups, h, nodes);
     BUILD_TRY(hipGetLastError());

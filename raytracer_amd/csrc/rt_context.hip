@@ -128,40 +128,56 @@ Box3 true_box(const rt_plane& p, const float* verts) {
     b.grow(); return b;
 }
 
-// ---- second-level hierarchy builder: median split on the widest centroid axis, runs of <= RT_SUB_LEAF entries
+// ---- second-level hierarchy builder on the host (rt_set_option("device_build", 0)): the layout of rt_build.hip - a
+// perfect binary tree in heap order from node_base, node j of level l owning the items at positions
+// [j*n >> l, (j+1)*n >> l) of an ordering made by median splits on the widest centroid axis, four entry slots per run
+// from 4 * (node_base + run).
 struct SubItem { unsigned entry; Box3 box; float cen[3]; };
-struct SubRef { int ref, cnt; Box3 box; };
 
 struct SubBuilder {
-    std::vector<float4>& nodes;      // 4 words per interior node
+    std::vector<float4>& nodes;      // 4 words per node, absolute indices
     std::vector<int>& entries;
-    int max_depth = 0;
+    std::vector<SubItem>* it = nullptr;
+    long long n = 0; int depth = 0, node_base = 0;
 
-    SubRef build(std::vector<SubItem>& it, size_t lo, size_t hi, int depth) {
-        max_depth = std::max(max_depth, depth);
-        SubRef out; out.box.clear();
-        if (hi - lo <= RT_SUB_LEAF) {
-            std::sort(it.begin() + (long)lo, it.begin() + (long)hi, [](const SubItem& a, const SubItem& b) { return a.entry < b.entry; });
-            out.ref = ~(int)entries.size(); out.cnt = (int)(hi - lo);
-            for (size_t i = lo; i < hi; ++i) { entries.push_back((int)it[i].entry); out.box.add(it[i].box); }
+    // reserves 2^depth node slots and 4 * 2^depth entry slots at the end of the arrays; returns node_base
+    int build_group(std::vector<SubItem>& items, int depth_) {
+        it = &items; n = (long long)items.size(); depth = depth_;
+        node_base = (int)(nodes.size() / 4);
+        nodes.resize(nodes.size() + 4 * ((size_t)1 << depth), f4(0, 0, 0, 0));
+        entries.resize(4 * (nodes.size() / 4), -1);
+        int ref, cnt;
+        rec(0, 0, ref, cnt);
+        return node_base;
+    }
+    Box3 rec(int level, long long j, int& ref, int& cnt) {
+        const size_t a = (size_t)((j * n) >> level), b = (size_t)(((j + 1) * n) >> level);
+        std::vector<SubItem>& v = *it;
+        Box3 out; out.clear();
+        if (level == depth) {
+            std::sort(v.begin() + (long)a, v.begin() + (long)b, [](const SubItem& x, const SubItem& y) { return x.entry < y.entry; });
+            const size_t e0 = 4 * ((size_t)node_base + (size_t)j);
+            for (size_t i = a; i < b; ++i) { entries[e0 + (i - a)] = (int)v[i].entry; out.add(v[i].box); }
+            ref = ~(int)e0; cnt = (int)(b - a);
             return out;
         }
         float cmn[3] = { INFINITY, INFINITY, INFINITY }, cmx[3] = { -INFINITY, -INFINITY, -INFINITY };
-        for (size_t i = lo; i < hi; ++i) for (int k = 0; k < 3; ++k) { cmn[k] = std::min(cmn[k], it[i].cen[k]); cmx[k] = std::max(cmx[k], it[i].cen[k]); }
+        for (size_t i = a; i < b; ++i) for (int k = 0; k < 3; ++k) { cmn[k] = std::min(cmn[k], v[i].cen[k]); cmx[k] = std::max(cmx[k], v[i].cen[k]); }
         int axis = 0;
         if (cmx[1] - cmn[1] > cmx[axis] - cmn[axis]) axis = 1;
         if (cmx[2] - cmn[2] > cmx[axis] - cmn[axis]) axis = 2;
-        size_t mid = lo + (hi - lo) / 2;
-        std::nth_element(it.begin() + (long)lo, it.begin() + (long)mid, it.begin() + (long)hi,
-                         [axis](const SubItem& a, const SubItem& b) { return a.cen[axis] < b.cen[axis] || (a.cen[axis] == b.cen[axis] && a.entry < b.entry); });
-        size_t me = nodes.size() / 4;
-        nodes.resize(nodes.size() + 4);
-        SubRef L = build(it, lo, mid, depth + 1), R = build(it, mid, hi, depth + 1);
-        nodes[me * 4 + 0] = f4(L.box.mn[0], L.box.mn[1], L.box.mn[2], as_f(L.ref));
-        nodes[me * 4 + 1] = f4(L.box.mx[0], L.box.mx[1], L.box.mx[2], as_f(L.cnt));
-        nodes[me * 4 + 2] = f4(R.box.mn[0], R.box.mn[1], R.box.mn[2], as_f(R.ref));
-        nodes[me * 4 + 3] = f4(R.box.mx[0], R.box.mx[1], R.box.mx[2], as_f(R.cnt));
-        out.ref = (int)me; out.cnt = 0; out.box = L.box; out.box.add(R.box);
+        const size_t mid = (size_t)(((2 * j + 1) * n) >> (level + 1));
+        if (mid > a && mid < b)
+            std::nth_element(v.begin() + (long)a, v.begin() + (long)mid, v.begin() + (long)b,
+                             [axis](const SubItem& x, const SubItem& y) { return x.cen[axis] < y.cen[axis] || (x.cen[axis] == y.cen[axis] && x.entry < y.entry); });
+        const size_t me = (size_t)node_base + (((size_t)1 << level) - 1) + (size_t)j;
+        int refL, cntL, refR, cntR;
+        Box3 L = rec(level + 1, 2 * j, refL, cntL), R = rec(level + 1, 2 * j + 1, refR, cntR);
+        nodes[me * 4 + 0] = f4(L.mn[0], L.mn[1], L.mn[2], as_f(refL));
+        nodes[me * 4 + 1] = f4(L.mx[0], L.mx[1], L.mx[2], as_f(cntL));
+        nodes[me * 4 + 2] = f4(R.mn[0], R.mn[1], R.mn[2], as_f(refR));
+        nodes[me * 4 + 3] = f4(R.mx[0], R.mx[1], R.mx[2], as_f(cntR));
+        ref = (int)me; cnt = 0; out = L; out.add(R);
         return out;
     }
 };
@@ -200,6 +216,7 @@ struct rt_ctx {
     bool count_rays = true;                  // frames with statistics count rays (off: stage times only, at the speed of plain frames)
     // 0 = chosen per launch (see enqueue_frame)
     int grid_primary = 0, grid_secondary = 0, grid_shadow = 0, grid_shade = 0;
+    bool replicate_reflections = true;       // soft shadows: first reflections traced gr_samples times, each with its own shadow samples
     bool fast_samples = true;                // soft-shadow sample rays: hardware reciprocals instead of IEEE division
     int lds_prims = 1;                       // tiny scenes: primitive records in LDS; 1 = shadow kernel only, 2 = extend too
     int device_build = 1;                    // hierarchies and leaf-order records are made on the GPU (rt_set_option)
@@ -354,6 +371,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "skip_unlit") == 0) { c->skip_unlit = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "count_rays") == 0) { c->count_rays = value != 0; return RT_OK; }
     if (std::strcmp(name, "fast_samples") == 0) { c->fast_samples = value != 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "replicate_reflections") == 0) { c->replicate_reflections = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "overlap") == 0) { c->overlap = value != 0; c->drop_graphs(); return RT_OK; }
     return c->fail(RT_ERR_ARG, "unknown option %s", name);
 }
@@ -559,12 +577,12 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
         Box3 raw; for (int k = 0; k < 3; ++k) { raw.mn[k] = b6[k]; raw.mx[k] = b6[3 + k]; }
         if (ns > 0) c->sphere_e = sphere_allowance(raw);
         BuildGroup g{}; g.pn = np; g.cn = nc; g.sn = ns; g.n = np + nc + ns; g.depth = rt_build_depth(g.n);
-        if (g.depth + 2 > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_STACK - 2);
-        c->n_file_nodes = (1ll << g.depth) - 1; c->n_file_entries = g.n; c->file_sub_depth = g.depth;
+        if (g.depth > RT_SUB_MAX_DEPTH) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_MAX_DEPTH);
+        c->n_file_nodes = 1ll << g.depth; c->n_file_entries = 4ll << g.depth; c->file_sub_depth = g.depth;   // one node slot stays unused
         RT_HIP(c, c->d_sub_nodes_file.resize((size_t)c->n_file_nodes * 4));
         RT_HIP(c, c->d_sub_entries_file.resize((size_t)c->n_file_entries));
         float fin[6];
-        RT_HIP(c, rt_build_hierarchies(s, d.fileset, &g, 1, g.n, c->sphere_e, c->d_sub_nodes_file.p, c->d_sub_entries_file.p, 0, fin));
+        RT_HIP(c, rt_build_hierarchies(s, d.fileset, &g, 1, g.n, c->sphere_e, c->d_sub_nodes_file.p, c->d_sub_entries_file.p, fin));
         for (int k = 0; k < 3; ++k) { all.mn[k] = fin[k]; all.mx[k] = fin[3 + k]; }
         c->file_sub_root = 0;
         // the host copies of the records are only needed by the host build
@@ -594,10 +612,10 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
             for (int i = 0; i < np; ++i) items.push_back(make_item(0, i, c->tb_planes[i]));
             for (int i = 0; i < nc; ++i) items.push_back(make_item(1, i, c->tb_cubes[i]));
             for (int i = 0; i < ns; ++i) items.push_back(make_item(2, i, c->tb_spheres[i]));
+            const int depth = rt_build_depth((long long)items.size());
+            if (depth > RT_SUB_MAX_DEPTH) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_MAX_DEPTH);
             SubBuilder sb{ c->h_sub_nodes_file, c->h_sub_entries_file };
-            SubRef root = sb.build(items, 0, items.size(), 0);
-            if (sb.max_depth + 2 > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_STACK - 2);
-            c->file_sub_root = root.ref; c->file_sub_depth = sb.max_depth;
+            c->file_sub_root = sb.build_group(items, depth); c->file_sub_depth = depth;
         }
         c->n_file_nodes = (long long)(c->h_sub_nodes_file.size() / 4); c->n_file_entries = (long long)c->h_sub_entries_file.size();
         RT_HIP(c, c->d_sub_nodes_file.upload(c->h_sub_nodes_file, s));
@@ -616,7 +634,8 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
     d.lights = c->d_lights.p; d.n_lights = sc->n_lights;
     d.sub_nodes = c->n_file_nodes ? c->d_sub_nodes_file.p : nullptr;
     d.sub_entries = c->d_sub_entries_file.p; d.file_sub_root = c->file_sub_root;
-    d.sub_stack_entries = std::max(4, c->file_sub_depth + 2);
+    d.file_sub_depth = c->file_sub_depth;
+    d.sub_stack_entries = d.sub_stack_entries_leaves = rt_sub_stack_entries(c->file_sub_depth);
     d.n_verts = sc->n_plane_verts;
     d.lds_prims = (!d.sub_nodes && rt_lds_prim_words(d) <= RT_LDS_PRIM_MAX_WORDS) ? c->lds_prims : 0;
     for (int k = 0; k < 3; ++k) d.center[k] = centre[k];
@@ -638,8 +657,8 @@ static int upload_bvh_impl(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes,
     DevScene& d = c->scene;
     d.n_nodes = 0; d.n_leaves = 0;
     d.sub_nodes = c->n_file_nodes ? c->d_sub_nodes_file.p : nullptr; d.sub_entries = c->d_sub_entries_file.p;
-    d.sub_stack_entries = std::max(4, c->file_sub_depth + 2);
-    int deepest = c->file_sub_depth;
+    d.sub_stack_entries = d.sub_stack_entries_leaves = rt_sub_stack_entries(c->file_sub_depth);
+    int deepest = c->file_sub_depth, deepest_leaf = 0;
     if (!nodes || n_nodes <= 0) return RT_OK;
     if (n_prim_ids < 0 || (n_prim_ids && !prim_ids)) return c->fail(RT_ERR_ARG, "bad prim_ids");
     const int np = c->np, nc = c->nc, ns = c->ns;
@@ -742,18 +761,18 @@ static int upload_bvh_impl(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes,
             if (cnt <= c->sub_min_group) continue;
             BuildGroup b{}; b.p0 = L.lp0; b.pn = L.n_planes; b.c0 = L.lc0; b.cn = L.n_cubes; b.s0 = L.ls0; b.sn = L.n_spheres;
             b.n = (int)cnt; b.depth = rt_build_depth(cnt); b.item_base = (int)n_items; b.node_base = (int)total_nodes;
-            if (b.depth + 2 > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_STACK - 2);
-            leaves[2 * g + 1].z = b.node_base; deepest = std::max(deepest, b.depth);
-            n_items += cnt; total_nodes += (1ll << b.depth) - 1;
+            if (b.depth > RT_SUB_MAX_DEPTH) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_MAX_DEPTH);
+            leaves[2 * g + 1].z = b.node_base; leaves[2 * g + 1].w = b.depth; deepest = std::max(deepest, b.depth); deepest_leaf = std::max(deepest_leaf, b.depth);
+            n_items += cnt; total_nodes += 1ll << b.depth;                 // heap order, one slot stays unused
             groups.push_back(b);
         }
-        total_entries += n_items;
+        total_entries = 4 * total_nodes;                                  // four entry slots per run, at 4 * (node_base + run)
         if (total_nodes > 0x7fffffffll / 4 || total_entries > 0x7fffffffll) return c->fail(RT_ERR_CAPACITY, "second-level hierarchies too large");
         RT_HIP(c, c->d_sub_nodes.resize((size_t)total_nodes * 4)); RT_HIP(c, c->d_sub_entries.resize((size_t)total_entries));
         if (c->n_file_nodes) RT_HIP(c, hipMemcpyAsync(c->d_sub_nodes.p, c->d_sub_nodes_file.p, sizeof(float4) * 4 * (size_t)c->n_file_nodes, hipMemcpyDeviceToDevice, s));
         if (c->n_file_entries) RT_HIP(c, hipMemcpyAsync(c->d_sub_entries.p, c->d_sub_entries_file.p, sizeof(int) * (size_t)c->n_file_entries, hipMemcpyDeviceToDevice, s));
         RT_HIP(c, rt_build_hierarchies(s, leafset, groups.data(), (int)groups.size(), n_items, c->sphere_e,
-                                       c->d_sub_nodes.p, c->d_sub_entries.p, c->n_file_entries, nullptr));
+                                       c->d_sub_nodes.p, c->d_sub_entries.p, nullptr));
     } else {
         std::vector<float4> lp, lc, ls;
         std::vector<float4> sub_nodes = c->h_sub_nodes_file;      // the file-order hierarchy keeps its node indices
@@ -778,10 +797,10 @@ static int upload_bvh_impl(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes,
                 for (int k = 0; k < L.n_planes; ++k) items.push_back(make_item(0, L.lp0 + k, c->tb_planes[(size_t)ids[k]]));
                 for (int k = 0; k < L.n_cubes; ++k) items.push_back(make_item(1, L.lc0 + k, c->tb_cubes[(size_t)ids[L.n_planes + k]]));
                 for (int k = 0; k < L.n_spheres; ++k) items.push_back(make_item(2, L.ls0 + k, c->tb_spheres[(size_t)ids[L.n_planes + L.n_cubes + k]]));
+                const int depth = rt_build_depth(cnt);
+                if (depth > RT_SUB_MAX_DEPTH) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_MAX_DEPTH);
                 SubBuilder sb{ sub_nodes, sub_entries };
-                SubRef root = sb.build(items, 0, items.size(), 0);
-                if (sb.max_depth + 2 > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_STACK - 2);
-                leaves[2 * g + 1].z = root.ref; deepest = std::max(deepest, sb.max_depth);
+                leaves[2 * g + 1].z = sb.build_group(items, depth); leaves[2 * g + 1].w = depth; deepest = std::max(deepest, depth); deepest_leaf = std::max(deepest_leaf, depth);
             }
         }
         total_nodes = (long long)(sub_nodes.size() / 4); total_entries = (long long)sub_entries.size();
@@ -800,7 +819,8 @@ static int upload_bvh_impl(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes,
     d.nodes = c->d_nodes.p; d.n_nodes = (int)out.size();
     d.leaves = c->d_leaves.p; d.n_leaves = (int)(leaves.size() / 2);
     d.leafset = leafset;
-    d.sub_stack_entries = std::max(4, deepest + 2);
+    d.sub_stack_entries = rt_sub_stack_entries(deepest); d.sub_stack_entries_leaves = rt_sub_stack_entries(deepest_leaf);
+    if (d.sub_stack_entries > RT_SUB_STACK) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy of depth %d needs more than %d stack entries", deepest, RT_SUB_STACK);
     d.lds_prims = (!d.sub_nodes && rt_lds_prim_words(d) <= RT_LDS_PRIM_MAX_WORDS) ? c->lds_prims : 0;
     c->have_bvh = true;
     return RT_OK;
@@ -899,7 +919,7 @@ static int make_plan(rt_ctx* c, const rt_config* cfg, int D, int L, bool texture
     double npp[RT_MAX_LEVELS + 2];         // worst-case hits per primary sample at level d
     {
         double a = 1.0, b = 0.0;           // hits whose path has / has not yet had its gr_samples-fold reflection
-        const bool replicate = cfg->soft_shadows && !cfg->glossy_reflect;
+        const bool replicate = cfg->soft_shadows && !cfg->glossy_reflect && c->replicate_reflections;
         for (int d = 0; d <= D; ++d) {
             npp[d] = a + b;
             if (cfg->glossy_reflect) { a = a * (double)(refl * gr + transp); }
@@ -1011,6 +1031,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     int fb = cfg->fallback; if (fb == 0) fb = 1;
     f.fallback_full = (fb == 1);
     f.light_radius = cfg->light_radius; f.seed = cfg->seed; f.fast_samples = c->fast_samples ? 1 : 0; f.count_stats = count_stats ? 1 : 0; f.skip_unlit = c->skip_unlit ? 1 : 0;
+    f.replicate = (cfg->soft_shadows && c->replicate_reflections) ? 1 : 0;
     f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y; f.n_local_tiles = (int)c->local_tiles.size(); f.local_tiles = c->d_local_tiles.p;
 
     const long long n_slots = (long long)c->local_tiles.size() * RT_TILE_PIX;

@@ -24,7 +24,9 @@
 #ifndef RT_SHADOW_WAVES
 #define RT_SHADOW_WAVES 5           // each mode's kernel fits 96 registers without spilling
 #endif
+#ifndef RT_SHADOW_WAVES_SUB
 #define RT_SHADOW_WAVES_SUB 4
+#endif
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -387,87 +389,140 @@ DEVI bool test_prims(const DevPrimSet& S, const Ray& r, bool mb, int p0, int pn,
 //     covers what a primitive test may report outside the primitive's true bounds (a cube test treats a
 //     direction component below 1e-5 as zero, which moves the reported point by up to 1e-5 x distance).
 // An interior node holds both children's boxes: (minL, refL) (maxL, cntL) (minR, refR) (maxR, cntR); ref >= 0 is an
-// interior node, ref < 0 a run of cnt entries starting at ~ref.  entry = class << 30 | index in the set.
+// interior node, ref < 0 a run of cnt entries starting at ~ref (a multiple of four).  entry = class << 30 | index in the set.
 // ---------------------------------------------------------------------------------------------------------
-struct SubRay { V3 om, op, rcp; };
+// Per-ray constants of the second-level walk.  A box is entered at max over axes of (near plane - origin) / d and left
+// at min over axes of (far plane - origin) / d; which plane is the near one depends only on the sign of d, and with
+// the reciprocal and the products origin * reciprocal formed once per ray a plane costs one select and one fused
+// multiply-add.  The origin is moved by `pad` away from the box on either side (what a primitive test may report
+// outside the primitive's true bounds), and the constants carry the slack for the rounding of this arithmetic (the
+// reciprocal is good to 1 ulp and the two products cancel when the origin lies near a plane), so that a box is only
+// ever skipped when the exact arithmetic would skip it too.
+struct SubRay { V3 rcp, cn, cf; bool px, py, pz; };
 
-// Entry and exit parameter of the ray against a box enlarged by the per-ray pad, with slack for the rounding of
-// the reciprocal-multiply.  A direction component too small to divide by carries the finite stand-in reciprocal
-// 1e30 (see sub_trace): the two products then have the signs of (min - origin) and (max - origin), so an origin
-// inside the padded slab yields (-huge, +huge), no constraint, and one outside yields two huge values of one sign,
-// a certain miss.
-DEVI void sub_child(const SubRay& q, float4 mn, float4 mx, float& tn, float& tf) {
-    float a0 = (mn.x - q.op.x) * q.rcp.x, b0 = (mx.x - q.om.x) * q.rcp.x;
-    float a1 = (mn.y - q.op.y) * q.rcp.y, b1 = (mx.y - q.om.y) * q.rcp.y;
-    float a2 = (mn.z - q.op.z) * q.rcp.z, b2 = (mx.z - q.om.z) * q.rcp.z;
-    float n0 = fminf(a0, b0), f0 = fmaxf(a0, b0), n1 = fminf(a1, b1), f1 = fmaxf(a1, b1), n2 = fminf(a2, b2), f2 = fmaxf(a2, b2);
-    tn = fmaxf(fmaxf(n0, n1), n2);
-    tf = fminf(fminf(f0, f1), f2);
-    float E = 2e-6f * fmaxf(fabsf(tn), fabsf(tf));
-    if (!(E < INFINITY)) E = 0.0f;                   // infinite bounds need no slack (and inf - inf must not appear)
-    tn -= E; tf += E;
+DEVI void sub_axis(float o, float d, float pad, float& rcp, float& cn, float& cf, bool& pos) {
+    pos = d >= 0.0f;
+    if (fabsf(d) > 1e-12f) {
+        rcp = __builtin_amdgcn_rcpf(d);
+        // d > 0: entered through the min plane, seen from origin + pad; left through the max plane, from origin - pad
+        const float on = pos ? o + pad : o - pad, of = pos ? o - pad : o + pad;
+        cn = -on * rcp; cf = -of * rcp;
+        cn -= 1e-6f * fabsf(cn) + 1e-30f; cf += 1e-6f * fabsf(cf) + 1e-30f;
+        if (!(cn == cn) || !(cf == cf)) { rcp = 0.0f; cn = -INFINITY; cf = INFINITY; }     // NaN origin or pad: no constraint
+    } else {
+        // zero, denormal-small or NaN component: this axis constrains nothing (a ray parallel to the slab and outside it
+        // is then visited needlessly, never skipped wrongly)
+        rcp = 0.0f; cn = -INFINITY; cf = INFINITY;
+    }
 }
 
-// Per-ray constants of the second-level walk: origin -/+ the pad that covers what a primitive test may report
-// outside the primitive's true bounds, and the reciprocal direction.  Computed once per ray, not once per group.
 DEVI SubRay make_sub_ray(const DevScene& sc, const Ray& r) {
     SubRay q;
     V3 dc = r.o - mk(sc.center[0], sc.center[1], sc.center[2]);
     float pad = 2e-5f * (__builtin_amdgcn_sqrtf(dot(dc, dc)) + sc.radius) + 1e-6f * sc.radius;
     if (!(pad >= 0.0f)) pad = INFINITY;          // NaN origin: nothing may be skipped
-    q.om = mk(r.o.x - pad, r.o.y - pad, r.o.z - pad); q.op = mk(r.o.x + pad, r.o.y + pad, r.o.z + pad);
-    // zero, denormal-small or NaN components get a huge finite reciprocal instead of inf / NaN
-    q.rcp = mk(fabsf(r.d.x) > 1e-12f ? __builtin_amdgcn_rcpf(r.d.x) : 1e30f, fabsf(r.d.y) > 1e-12f ? __builtin_amdgcn_rcpf(r.d.y) : 1e30f,
-               fabsf(r.d.z) > 1e-12f ? __builtin_amdgcn_rcpf(r.d.z) : 1e30f);
+    sub_axis(r.o.x, r.d.x, pad, q.rcp.x, q.cn.x, q.cf.x, q.px);
+    sub_axis(r.o.y, r.d.y, pad, q.rcp.y, q.cn.y, q.cf.y, q.py);
+    sub_axis(r.o.z, r.d.z, pad, q.rcp.z, q.cn.z, q.cf.z, q.pz);
     return q;
 }
 
+// Entry and exit parameter of the ray against a box.  A non-finite bound times a zero reciprocal gives NaN, which fails
+// every comparison of the caller and makes it visit the box.
+DEVI void sub_child(const SubRay& q, float4 mn, float4 mx, float& tn, float& tf) {
+    const float nx = q.px ? mn.x : mx.x, fx = q.px ? mx.x : mn.x;
+    const float ny = q.py ? mn.y : mx.y, fy = q.py ? mx.y : mn.y;
+    const float nz = q.pz ? mn.z : mx.z, fz = q.pz ? mx.z : mn.z;
+    const float n0 = __builtin_fmaf(nx, q.rcp.x, q.cn.x), f0 = __builtin_fmaf(fx, q.rcp.x, q.cf.x);
+    const float n1 = __builtin_fmaf(ny, q.rcp.y, q.cn.y), f1 = __builtin_fmaf(fy, q.rcp.y, q.cf.y);
+    const float n2 = __builtin_fmaf(nz, q.rcp.z, q.cn.z), f2 = __builtin_fmaf(fz, q.rcp.z, q.cf.z);
+    tn = fmaxf(fmaxf(n0, n1), n2);
+    tf = fminf(fminf(f0, f1), f2);
+    const float m = fmaxf(fabsf(tn), fabsf(tf));     // relative slack for the products' own rounding
+    tn = __builtin_fmaf(-1e-6f, m, tn); tf = __builtin_fmaf(1e-6f, m, tf);
+}
+
+// Layout the walk relies on: a group's hierarchy is a perfect binary tree in heap order (node h of the group sits at
+// root + h, its children at root + 2h + 1 and root + 2h + 2, the levels 0 .. depth - 1 are interior, the children of
+// level depth - 1 are runs), and run j of the group owns the four entry slots 4 * (root + j) .. + 3 (unused slots hold
+// -1).  Siblings are adjacent in memory, so one step can skip a level: instead of the node's own record (the boxes of
+// its two children) it loads the records of both children (128 contiguous bytes, address known from the heap index
+// alone) and tests the four grandchildren - half as many dependent round trips to memory per ray.  All children of a
+// step are of one kind: interior nodes, or (below level depth - 2) runs.
 template <bool ANY, bool FAST>
-DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, const Ray& r, const SubRay& q, bool mb, bool leaf_rule,
+DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth, const Ray& r, const SubRay& q, bool mb, bool leaf_rule,
                     float stop_below, int* __restrict__ stack, Best& best) {
     float best_t = leaf_rule ? INFINITY : FLT_MAX;
     unsigned best_key = 0u; bool has = false;
-    int sp = 0, node = root;
+    int sp = 0, h = 0;                                        // h = heap index inside the group
+    const int first_run = (1 << depth) - 1;                   // heap index the first run would have
     for (;;) {
-        const float4* __restrict__ nd = sc.sub_nodes + 4 * (size_t)node;
-        float4 lmn = nd[0], lmx = nd[1], rmn = nd[2], rmx = nd[3];
-        float ltn, ltf, rtn, rtf;
-        sub_child(q, lmn, lmx, ltn, ltf);
-        sub_child(q, rmn, rmx, rtn, rtf);
-        // skip only on a certain miss; any NaN makes the comparisons false and the child is visited
-        bool goL = !(ltn > ltf) && !(ltf < 0.0f) && !(ltn > best_t);
-        bool goR = !(rtn > rtf) && !(rtf < 0.0f) && !(rtn > best_t);
-        int refL = f2i(lmn.w), refR = f2i(rmn.w), cntL = f2i(lmx.w), cntR = f2i(rmx.w);
-        // entry runs are tested on the spot, interior children are descended into (nearer first)
+        const int level = 31 - __clz(h + 1);
+        const bool wide = level + 2 <= depth;                 // the children are interior nodes: step to the grandchildren
+        const bool runs = level + 2 >= depth;                 // what this step tests are runs of entries
+        const int kid0 = wide ? 4 * h + 3 : 2 * h + 1;        // heap index of the first child tested
+        const float4* __restrict__ nd = sc.sub_nodes + 4 * (size_t)(root + (wide ? 2 * h + 1 : h));
+        float4 bx[8];
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const bool go = side ? goR : goL; const int ref = side ? refR : refL, cnt = side ? cntR : cntL;
-            if (go && ref < 0) {
-                const int first = ~ref;
-                for (int e = first; e < first + cnt; ++e) {
-                    const unsigned entry = (unsigned)sc.sub_entries[e];
-                    const int cls = (int)(entry >> 30), idx = (int)(entry & 0x3fffffffu);
-                    float t; bool ok;
-                    if (cls == 0) ok = plane_test<false, FAST>(S.planes + 3 * idx, S.edges, nullptr, r, false, t, nullptr);
-                    else if (cls == 1) ok = cube_test<false, FAST>(S.cubes + 6 * idx, r, mb, false, t, nullptr);
-                    else ok = sphere_test<false, FAST>(S.spheres + 2 * idx, r, mb, false, t, nullptr);
-                    if (ok && (!leaf_rule || t >= 0.0f) && (t < best_t || (has && t == best_t && entry < best_key))) {
-                        has = true; best_t = t; best_key = entry; best.t = t; best.cls = cls; best.idx = idx;
-                        if (ANY || t < stop_below) return true;
+        for (int k = 0; k < 4; ++k) bx[k] = nd[k];
+        if (wide) {
+#pragma unroll
+            for (int k = 4; k < 8; ++k) bx[k] = nd[k];
+        }
+        float tn4[4]; bool go4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float tn = 0.0f, tf = 0.0f;
+            if (k < 2 || wide) sub_child(q, bx[2 * k], bx[2 * k + 1], tn, tf);
+            // skip only on a certain miss; any NaN makes the comparisons false and the child is visited
+            go4[k] = (k < 2 || wide) && !(tn > tf) && !(tf < 0.0f) && !(tn > best_t);
+            tn4[k] = tn;
+        }
+        if (runs) {
+            // entry runs are tested on the spot
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (go4[k] && !(tn4[k] > best_t)) {
+                    const int4 ev = *(const int4*)(sc.sub_entries + 4 * (size_t)(root + kid0 + k - first_run));
+#pragma unroll
+                    for (int e = 0; e < RT_SUB_LEAF; ++e) {
+                        const unsigned entry = (unsigned)(e == 0 ? ev.x : e == 1 ? ev.y : e == 2 ? ev.z : ev.w);
+                        if (entry == 0xffffffffu) break;
+                        const int cls = (int)(entry >> 30), idx = (int)(entry & 0x3fffffffu);
+                        float t; bool ok;
+                        if (cls == 0) ok = plane_test<false, FAST>(S.planes + 3 * idx, S.edges, nullptr, r, false, t, nullptr);
+                        else if (cls == 1) ok = cube_test<false, FAST>(S.cubes + 6 * idx, r, mb, false, t, nullptr);
+                        else ok = sphere_test<false, FAST>(S.spheres + 2 * idx, r, mb, false, t, nullptr);
+                        if (ok && (!leaf_rule || t >= 0.0f) && (t < best_t || (has && t == best_t && entry < best_key))) {
+                            has = true; best_t = t; best_key = entry; best.t = t; best.cls = cls; best.idx = idx;
+                            if (ANY || t < stop_below) return true;
+                        }
                     }
                 }
             }
-        }
-        const bool inL = goL && refL >= 0 && !(ltn > best_t), inR = goR && refR >= 0 && !(rtn > best_t);
-        if (inL && inR) {
-            const bool leftFirst = !(rtn < ltn);
-            stack[sp * RT_BLOCK] = leftFirst ? refR : refL; ++sp;
-            node = leftFirst ? refL : refR;
-        } else if (inL) node = refL;
-        else if (inR) node = refR;
-        else {
             if (sp == 0) break;
-            --sp; node = stack[sp * RT_BLOCK];
+            --sp; h = stack[sp * RT_BLOCK];
+            continue;
+        }
+        // interior children worth a visit, nearest first: sort keys = entry distance (never negative here; NaN counts as
+        // nearest) with the child number in the two lowest bits
+        unsigned key[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d = (tn4[k] > 0.0f) ? tn4[k] : 0.0f;                      // NaN and negative distances: 0
+            key[k] = go4[k] ? ((__float_as_uint(d) & ~3u) | (unsigned)k) : 0xffffffffu;
+        }
+#define RT_CSWAP(i, j) do { const unsigned lo = min(key[i], key[j]), hi = max(key[i], key[j]); key[i] = lo; key[j] = hi; } while (0)
+        RT_CSWAP(0, 1); RT_CSWAP(2, 3); RT_CSWAP(0, 2); RT_CSWAP(1, 3); RT_CSWAP(1, 2);
+#undef RT_CSWAP
+        if (key[0] != 0xffffffffu) {
+            if (key[3] != 0xffffffffu) { stack[sp * RT_BLOCK] = kid0 + (int)(key[3] & 3u); ++sp; }
+            if (key[2] != 0xffffffffu) { stack[sp * RT_BLOCK] = kid0 + (int)(key[2] & 3u); ++sp; }
+            if (key[1] != 0xffffffffu) { stack[sp * RT_BLOCK] = kid0 + (int)(key[1] & 3u); ++sp; }
+            h = kid0 + (int)(key[0] & 3u);
+        } else {
+            if (sp == 0) break;
+            --sp; h = stack[sp * RT_BLOCK];
         }
     }
     return has;
@@ -477,8 +532,8 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, const Ray
 // SUB = the scene has at least one second-level hierarchy (kernels for small scenes are compiled without that code).
 template <bool ANY, bool SUB, bool FAST>
 DEVI bool test_group(const DevScene& sc, const DevPrimSet& S, const Ray& r, const SubRay& q, bool mb, int p0, int pn, int c0, int cn, int s0, int sn,
-                     int sub_root, bool leaf_rule, float stop_below, int* __restrict__ stack, Best& best) {
-    if (SUB && sub_root >= 0) return sub_trace<ANY, FAST>(sc, S, sub_root, r, q, mb, leaf_rule, stop_below, stack, best);
+                     int sub_root, int sub_depth, bool leaf_rule, float stop_below, int* __restrict__ stack, Best& best) {
+    if (SUB && sub_root >= 0) return sub_trace<ANY, FAST>(sc, S, sub_root, sub_depth, r, q, mb, leaf_rule, stop_below, stack, best);
     return test_prims<ANY, FAST>(S, r, mb, p0, pn, c0, cn, s0, sn, leaf_rule, stop_below, best);
 }
 
@@ -493,7 +548,7 @@ template <bool ANY, bool SUB, bool FAST = false>
 DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict__ nodes, const int4* __restrict__ leaves,
                 int* __restrict__ stack, const Ray& r, bool with_fallback, Best& best, float stop_below = -INFINITY) {
     const bool mb = f.motion_blur != 0;
-    SubRay q; q.om = q.op = q.rcp = mk(0.0f, 0.0f, 0.0f);
+    SubRay q; q.rcp = q.cn = q.cf = mk(0.0f, 0.0f, 0.0f); q.px = q.py = q.pz = true;
     if (SUB) q = make_sub_ray(sc, r);
     if (f.use_bvh) {
         int i = 0;
@@ -509,17 +564,17 @@ DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict_
             ++i;
             if (leaf >= 0) {
                 int4 l0 = leaves[2 * leaf], l1 = leaves[2 * leaf + 1];
-                if (test_group<ANY, SUB, FAST>(sc, sc.leafset, r, q, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, true, stop_below, stack, best)) { best.fileset = 0; return true; }
+                if (test_group<ANY, SUB, FAST>(sc, sc.leafset, r, q, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, true, stop_below, stack, best)) { best.fileset = 0; return true; }
             }
         }
         if (!with_fallback) return false;
         best.fileset = 1;
         return test_group<false, SUB, FAST>(sc, sc.fileset, r, q, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
-                                 sc.file_sub_root, false, stop_below, stack, best);
+                                 sc.file_sub_root, sc.file_sub_depth, false, stop_below, stack, best);
     }
     best.fileset = 1;
     return test_group<ANY, SUB, FAST>(sc, sc.fileset, r, q, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
-                           sc.file_sub_root, false, stop_below, stack, best);
+                           sc.file_sub_root, sc.file_sub_depth, false, stop_below, stack, best);
 }
 
 DEVI void full_hit(const DevScene& sc, const DevFrame& f, const Ray& r, const Best& best, HitOut& h) {
@@ -757,7 +812,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
                     // reflection of a path is therefore traced gr_samples times for real (distinct path ids, so distinct
                     // sample sets); below it, where a contribution carries reflectivity^2 or less, identical rays are
                     // traced once again (the reference would trace gr_samples^depth of them).
-                    n_reflect = (glossy || (f.soft_shadows && !replicated)) ? f.gr_samples : 1;
+                    n_reflect = (glossy || (f.replicate && !replicated)) ? f.gr_samples : 1;
                 }
                 if (transparency > 0) {                                  // raytracer.cpp:444-497
                     float n1 = 1.0f, n2 = ior;
@@ -817,7 +872,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
             const float EPS = 1e-4f;
             // multiplicity of the children: each of the reference's gr_samples copies of a deduplicated ray
             unsigned long long cm = (unsigned long long)mult * (unsigned)(n_reflect == 1 ? f.gr_samples : 1);
-            const uint32_t flag_refl = (replicated || (f.soft_shadows && !glossy)) ? 0x80000000u : 0u;
+            const uint32_t flag_refl = (replicated || (f.replicate && !glossy)) ? 0x80000000u : 0u;
             const uint32_t child_mult = (cm > 0x7fffffffull ? 0x7fffffffu : (uint32_t)cm) | flag_refl;
             for (int j = 0; j < n_reflect; ++j) {                        // raytracer.cpp:415-421
                 V3 dir = rd;
@@ -1167,16 +1222,18 @@ __global__ void k_begin_frame(uint4* __restrict__ zero, size_t n_words, int tail
 // LDS per workgroup: the first-level nodes and leaf records (BVH mode) and, when any group of primitives has a
 // second-level hierarchy, one traversal stack per thread.  The kernels index from n_nodes / n_leaves, which the
 // context zeroes when no BVH is uploaded.
-static size_t bvh_lds_bytes(const DevScene& sc, const DevFrame& f) {
+// file_set: the launch may walk the hierarchy of the whole file-order set (-u, or the retry of secondary rays), which is
+// deeper than any leaf's and needs the longer stack.
+static size_t bvh_lds_bytes(const DevScene& sc, const DevFrame& f, bool file_set) {
     size_t b = (size_t)(2 * sc.n_nodes) * 16;
-    if (sc.sub_nodes) b += (size_t)RT_BLOCK * (size_t)sc.sub_stack_entries * sizeof(int);
+    if (sc.sub_nodes) b += (size_t)RT_BLOCK * (size_t)(file_set ? sc.sub_stack_entries : sc.sub_stack_entries_leaves) * sizeof(int);
     else b += (size_t)(2 * sc.n_leaves) * 16;
     if (sc.lds_prims) b += (size_t)rt_lds_prim_words(sc) * 16;
     return b ? b : 16;
 }
 
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {
-    size_t lds = bvh_lds_bytes(sc, f);
+    size_t lds = bvh_lds_bytes(sc, f, !f.use_bvh || (level > 0 && f.fallback_full));
     const bool sub = sc.sub_nodes != nullptr;
     const bool ldsp = !sub && sc.lds_prims > 1;
 #define RT_EXTEND_LAUNCH(PRIMARY, SUB, LDSP) \
@@ -1195,7 +1252,7 @@ void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, cons
 }
 
 void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid) {
-    const size_t lds = bvh_lds_bytes(sc, f);
+    const size_t lds = bvh_lds_bytes(sc, f, !f.use_bvh);
     const int mode = !f.soft_shadows ? 0 : (f.fast_samples ? 2 : 1);  // hard shadows are deterministic: always exact
 #define RT_SHADOW_LAUNCH(SUB, LDSP) \
     do { if (mode == 2) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 2>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); \

@@ -14,7 +14,8 @@
 #define RT_MAX_LDS_LEAVES  512       // leaf records staged in LDS (32 B each)
 #define RT_SUB_LEAF        4         // second-level hierarchy: primitives per entry run
 #define RT_SUB_MIN_GROUP   8         // groups of at most this many primitives are tested one by one
-#define RT_SUB_STACK       26        // most second-level traversal stack entries per thread (LDS); a scene uses depth + 2
+#define RT_SUB_STACK       40        // most second-level traversal stack entries per thread (LDS); see rt_sub_stack_entries
+#define RT_SUB_MAX_DEPTH   24        // deepest second-level hierarchy (16M runs)
 
 // ---- primitives ---------------------------------------------------------------------------------------
 // A primitive set is one ordering of the scene's primitives: leaf order (BVH traversal) or file order
@@ -46,8 +47,9 @@ struct DevPrimSet {
 // BVH node : 2 words (min.xyz, bits skip) (max.xyz, bits leaf | -1), laid out in the order a traversal that
 //            visits the right child first meets them; skip = index of the next node once this subtree is done.
 // leaf     : 2 words of ints (plane_first, plane_count, cube_first, cube_count)
-//            (sphere_first, sphere_count, second-level root | -1, 0)
-// second-level node : 4 words, see sub_trace in rt_kernels.hip; entries: class << 30 | index in the primitive set
+//            (sphere_first, sphere_count, second-level root | -1, depth of that hierarchy)
+// second-level node : 4 words, heap order per group, see sub_trace in rt_kernels.hip; entries: four slots per run,
+//            class << 30 | index in the primitive set, or -1
 struct DevScene {
     const float4* nodes;  int n_nodes;
     const int4* leaves;   int n_leaves;
@@ -61,7 +63,9 @@ struct DevScene {
     const float4* sub_nodes;       // second-level hierarchies of all groups (NULL when no group has one)
     const int* sub_entries;
     int file_sub_root;             // second-level root over the whole file-order set, or -1
-    int sub_stack_entries;         // traversal stack entries per thread = deepest hierarchy + 2
+    int file_sub_depth;            // depth of that hierarchy
+    int sub_stack_entries;         // traversal stack entries per thread, see rt_sub_stack_entries: any hierarchy of the scene
+    int sub_stack_entries_leaves;  // the same for walks that only enter the leaves' hierarchies (not the file-order set's)
     int n_verts;                   // polygon vertices of all planes
     int lds_prims;                 // tiny scene: kernels keep the primitive records and materials in LDS
     float center[3], radius;       // sphere around the true bounds of everything in the scene
@@ -79,6 +83,7 @@ struct DevFrame {
     uint32_t seed;
     int fast_samples;              // randomly drawn shadow rays use reciprocal arithmetic (distribution-level parity)
     int skip_unlit;                // shadow rays of (hit, light) pairs whose N.L is clearly negative are not traced
+    int replicate;                 // soft shadows: the first reflection of a path is traced gr_samples times (see k_extend)
     int count_stats;               // kernels add their ray counts to DevWork::stats (one atomic per workgroup and counter)
     // sharding
     int tiles_x, tiles_y, n_local_tiles;
@@ -148,6 +153,10 @@ static inline int rt_lds_prim_words(const DevScene& sc) {
     return sc.n_verts + 3 * (sc.fileset.n_planes + sc.leafset.n_planes) + 6 * (sc.fileset.n_cubes + sc.leafset.n_cubes) +
            2 * (sc.fileset.n_spheres + sc.leafset.n_spheres) + 3 * (sc.fileset.n_planes + sc.fileset.n_cubes + sc.fileset.n_spheres);
 }
+
+// Stack entries a walk of a hierarchy of `depth` levels needs: a step that skips a level pushes up to three siblings,
+// and there are ceil(depth / 2) such steps on a root-to-run path.
+static inline int rt_sub_stack_entries(int depth) { return 3 * ((depth + 1) / 2) + 2; }
 
 // kernel launchers (rt_kernels.hip)
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);

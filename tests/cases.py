@@ -34,7 +34,20 @@ def blend_scene(name: str, w: int, h: int) -> str:
     return with_resolution((GOLDEN / "scenes" / f"{name}.json").read_text(), w, h)
 
 
+def mirror_scene(res=(200, 112)) -> str:
+    """A fully lit, strongly reflecting wall behind a sphere that hovers over a matt floor: the wall's own shading is
+    deterministic, the soft shadow on the floor is seen only through the reflection."""
+    cams = [sg.camera(location=(0, -6, 2.5), gaze=(0, 1, -0.2), res=res)]
+    lights = [sg.light((3, -2, 7), 400.0)]
+    floor = sg.plane([(-8, -8, 0), (8, -8, 0), (-8, 8, 0), (8, 8, 0)], sg.material((0.6, 0.6, 0.6), (0, 0, 0), 10.0))
+    wall = sg.plane([(-7, 6, 0), (7, 6, 0), (-7, 6, 7), (7, 6, 7)], sg.material((0.05, 0.05, 0.05), (1, 1, 1), 200.0))
+    ball = sg.sphere((0.5, 1.5, 3.0), 0.9, sg.material((0.8, 0.3, 0.2), (0, 0, 0), 10.0))
+    box = sg.cube((-3, 3, 0.5), 0.5, sg.material((0.2, 0.3, 0.8), (0, 0, 0), 10.0), (0, 0, 0.4))
+    return sg.scene_text(cams, lights, [ball], [box], [floor, wall])
+
+
 SCENES = {
+    "mirror": mirror_scene,
     "ref": lambda: reference_scene(240, 135),
     # the reference's own Blender scenes
     "bvh5": lambda: blend_scene("bvh_vs_unaccel_5", 240, 135),
@@ -112,8 +125,35 @@ STOCHASTIC = [
     # the reference's motion-blur scene and its 18-object scene with soft shadows
     ("cube_mb", ["-m", "-mbs", "256"]),
     ("bvh5", ["-ss", "-sss", "256"]),
+    # soft shadows below the primary hit: computeSoftShadows runs inside blinnPhong at every recursion level
+    # (raytracer.cpp:330-332 under :366)
+    ("ref", ["-rd", "2", "-grs", "1", "-ss", "-sss", "256"]),
+    ("glass_tex", ["-t", "-rd", "2", "-grs", "1", "-ss", "-sss", "256"]),
+    ("bvh5", ["-r", "-grs", "1", "-ss", "-sss", "128"]),
 ]
+
+# A crowded random scene with every effect that has a sample count switched on at once (moving primitives in
+# second-level hierarchies, soft shadows, reflection and refraction).  The reference needs hours for this frame on one
+# core, so the high-sample image comes from the CPU restatement rendered in horizontal bands on all cores (each band
+# with its own rand() seed: a sample of the same distribution, not the byte-exact image of the reference binary).
+STOCHASTIC_BANDED = [
+    ("rand2k", ["-t", "-m", "-mbs", "64", "-ss", "-sss", "64", "-r", "-grs", "1"]),
+]
+BANDS = 24
 
 
 def case_id(scene: str, flags: list[str]) -> str:
     return scene + ("_" + "".join(f.replace("-", "") for f in flags) if flags else "_default")
+
+
+# Cases judged against the sampling noise itself: two renders of the CPU restatement with different rand() seeds
+# (seed 1 = the reference binary's own output) give the noise floor a GPU render has to sit on.
+NOISE_FLOOR = [
+    ("glass_tex", ["-t", "-aa", "-aas", "16", "-ss", "-sss", "16", "-r", "-grs", "1"]),
+    ("ref", ["-aa", "-aas", "4", "-dof", "-dofs", "8", "-m", "-mbs", "8", "-ss", "-sss", "8"]),
+]
+# Per-pixel mean and variance over MIRROR_SEEDS renders of the mirror scene: soft shadows seen through gr_samples
+# identical reflection rays, each of which draws its own shadow samples in the reference
+MIRROR_FLAGS = ["-r", "-ss", "-sss", "4"]
+MIRROR_DIRECT_FLAGS = ["-ss", "-sss", "4"]
+MIRROR_SEEDS = 48

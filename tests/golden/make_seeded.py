@@ -1,0 +1,75 @@
+"""Fixtures that need renders with several rand() seeds, which only the CPU restatement offers (the reference never
+calls srand; the restatement with seed 1 reproduces the reference binary byte for byte, checked below where the
+binary exists).  Output: seeded.npz
+  floor_<case>_seed1 / _seed2 : uint8 images of cases.NOISE_FLOOR
+  mirror_direct_var           : per-pixel variance (summed over channels) of the mirror scene without reflection
+  mirror_mean, mirror_var     : per-pixel mean image and variance (summed over channels) with cases.MIRROR_FLAGS
+  banded_<case>               : uint8 images of cases.STOCHASTIC_BANDED, rendered in cases.BANDS horizontal bands (band b
+                                with rand() seed 1 + b), for flag sets the reference binary needs hours for
+Usage: make_seeded.py [floor] [mirror] [banded]   (default: all; parts not named are kept from the existing file)
+"""
+import sys
+from concurrent.futures import ProcessPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent))
+import cases  # noqa: E402
+import oracle  # noqa: E402
+import ref_runner  # noqa: E402
+
+TEX = str(cases.TEXTURES)
+
+
+def render(job):
+    scene, flags, seed = job
+    return oracle.render(cases.SCENES[scene](), flags, TEX, rand_seed=seed)[0]
+
+
+def mirror_stats(pool_map=map):
+    seeds = range(1, cases.MIRROR_SEEDS + 1)
+    a = np.stack(list(pool_map(render, [("mirror", cases.MIRROR_DIRECT_FLAGS, s) for s in seeds]))).astype(np.float64)
+    b = np.stack(list(pool_map(render, [("mirror", cases.MIRROR_FLAGS, s) for s in seeds]))).astype(np.float64)
+    return a.var(axis=0).sum(axis=2).astype(np.float32), b.mean(axis=0).astype(np.float32), b.var(axis=0).sum(axis=2).astype(np.float32)
+
+
+def render_band(job):
+    scene, flags, band = job
+    text = cases.SCENES[scene]()
+    w, h = ref_runner.get_resolution(text)
+    y0, y1 = (h * band) // cases.BANDS, (h * (band + 1)) // cases.BANDS
+    img = oracle.render(text, flags, TEX, rand_seed=1 + band, window=(0, y0, w, y1))[0]
+    return y0, y1, img[y0:y1]
+
+
+def main():
+    parts = set(sys.argv[1:]) or {"floor", "mirror", "banded"}
+    path = HERE / "seeded.npz"
+    out = dict(np.load(path)) if path.exists() else {}
+    with ProcessPoolExecutor(max_workers=7) as ex:
+        if "floor" in parts:
+            jobs = [(s, f, seed) for s, f in cases.NOISE_FLOOR for seed in (1, 2)]
+            for (s, f, seed), img in zip(jobs, ex.map(render, jobs)):
+                out[f"floor_{cases.case_id(s, f)}_seed{seed}"] = img.astype(np.uint8)
+                if seed == 1 and ref_runner.have_ref():
+                    ref, _, _ = ref_runner.run_ref(cases.SCENES[s](), f, {p.name: p for p in cases.TEXTURES.glob("*.ppm")})
+                    assert np.array_equal(ref, img), "seed 1 must be the reference binary's own image"
+                    print(f"{cases.case_id(s, f)}: seed 1 equals the reference binary")
+        if "mirror" in parts:
+            out["mirror_direct_var"], out["mirror_mean"], out["mirror_var"] = mirror_stats(ex.map)
+        if "banded" in parts:
+            for s, f in cases.STOCHASTIC_BANDED:
+                w, h = ref_runner.get_resolution(cases.SCENES[s]())
+                img = np.zeros((h, w, 3), dtype=np.uint8)
+                for y0, y1, band in ex.map(render_band, [(s, f, b) for b in range(cases.BANDS)]):
+                    img[y0:y1] = band
+                out[f"banded_{cases.case_id(s, f)}"] = img
+    np.savez_compressed(path, **out)
+    for k, v in out.items():
+        print(k, v.shape, v.dtype)
+
+
+if __name__ == "__main__":
+    main()

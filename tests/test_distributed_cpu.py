@@ -83,3 +83,25 @@ def test_tile_ownership_is_balanced_and_complete():
             for r in range(world):                       # slot indices are 0..count-1 in ascending tile order
                 ks = [k for (tx, ty), (o, k) in sorted(slots.items(), key=lambda kv: (kv[0][1], kv[0][0])) if o == r]
                 assert ks == list(range(len(ks)))
+
+
+def test_bench_starts_its_own_ranks_when_asked_for_several_gpus():
+    """`python bench.py --gpus 2` without a torchrun environment: the script starts the ranks itself (a child
+    torch.distributed.run), the ranks initialise the process group (gloo here) and reduce one number, rank 0's line comes
+    back through the parent, which passes the child's exit status on."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(cases.ROOT / "bench.py"), "--gpus", "2", "--single-device", "--backend", "gloo", "--launch-check"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out == {"launch_check": "ok", "world": 2, "sum_of_ranks_plus_one": 3.0}
+    # a --gpus count that contradicts the launcher's world size is refused, with the child's status passed on
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, str(cases.ROOT / "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=120, env=env2)
+    assert p.returncode == 2

@@ -1,0 +1,123 @@
+"""Soft shadows on the path the headline configuration uses: below the primary hit (computeSoftShadows is called from
+blinnPhong at every recursion level, raytracer.cpp:330-332 under :366), with 16 samples (the wavefront-ballot count
+in k_shadow), and seen through the gr_samples identical reflection rays of raytracer.cpp:400-432.  All through the C ABI.
+
+The generator here is a counter-based hash, the reference's is glibc rand(): images are compared as distributions -
+means over many seeds against the reference's high-sample renders, per-pixel variances against the CPU restatement's
+over as many seeds, and single renders against the noise floor two CPU renders with different seeds have between them."""
+import copy
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+from raytracer_amd import api
+
+pytestmark = pytest.mark.gpu
+
+STO = np.load(cases.GOLDEN / "stochastic.npz")
+SEEDED = np.load(cases.GOLDEN / "seeded.npz")
+
+
+def psnr(a, b):
+    mse = np.mean((np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)) ** 2)
+    return 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+
+
+def render_seeds(scene, flags, seeds, textures_dir, options=None):
+    cfg, _ = api.parse_args(flags)
+    ls = api.LoadedScene(cases.SCENES[scene](), cfg, textures_dir)
+    r = api.Renderer(0)
+    for k, v in (options or {}).items():
+        r.set_option(k, v)
+    r.upload(ls, with_bvh=bool(cfg.bvh))
+    imgs, stats = [], None
+    for s in seeds:
+        c = copy.copy(cfg); c.seed = s
+        img, stats = r.render(c)
+        imgs.append(img)
+    r.close(); ls.close()
+    return np.stack(imgs), stats
+
+
+@pytest.mark.parametrize("flags,golden", [(["-ss", "-sss", "16"], ("ref", ["-ss", "-sss", "256"])),
+                                          (["-rd", "2", "-ss", "-sss", "16"], ("ref", ["-rd", "2", "-grs", "1", "-ss", "-sss", "256"])),
+                                          (["-rd", "2", "-grs", "1", "-ss", "-sss", "16"], ("ref", ["-rd", "2", "-grs", "1", "-ss", "-sss", "256"]))])
+def test_sixteen_sample_soft_shadows_average_to_the_reference_high_sample_render(flags, golden, textures_dir):
+    """-sss 16 is the sample count of the headline configuration: a (hit, light) group is a quarter of a wavefront and
+    its unblocked samples are counted with a ballot.  Sixteen renders with different seeds, averaged, are a 256-sample
+    estimate and must agree with the reference's 256-sample render, at depth 0 and below reflections."""
+    imgs, _ = render_seeds("ref", flags, range(1, 17), textures_dir)
+    mean = imgs.astype(np.float64).mean(axis=0)
+    p = psnr(mean, STO[cases.case_id(*golden)])
+    assert p >= 40.0, f"PSNR {p:.1f} dB"
+    for fast in (0,):                                    # the reference's arithmetic for the sample rays gives the same picture
+        exact, _ = render_seeds("ref", flags, range(1, 17), textures_dir, {"fast_samples": fast})
+        assert psnr(exact.astype(np.float64).mean(axis=0), STO[cases.case_id(*golden)]) >= 40.0
+
+
+@pytest.mark.parametrize("scene,flags", cases.NOISE_FLOOR, ids=[cases.case_id(s, f) for s, f in cases.NOISE_FLOOR])
+def test_low_sample_renders_sit_on_the_noise_floor_of_the_reference(scene, flags, textures_dir):
+    """Flag sets with a few hundred samples per pixel in all are noisy on both sides.  Two renders of the CPU restatement
+    with different rand() seeds (seed 1 is the reference binary's own image, byte for byte) differ by the sampling noise
+    alone; a GPU render must be as close to the reference's image as that, and two GPU seeds as close to each other."""
+    cid = cases.case_id(scene, flags)
+    o1, o2 = SEEDED[f"floor_{cid}_seed1"], SEEDED[f"floor_{cid}_seed2"]
+    floor = psnr(o1, o2)
+    imgs, _ = render_seeds(scene, flags, (1, 2), textures_dir)
+    g1, g2 = imgs
+    assert floor < 40.0                                   # these cases are here because they cannot reach the 40 dB bar
+    assert psnr(g1, o1) >= floor - 1.0, f"GPU vs reference {psnr(g1, o1):.1f} dB, noise floor {floor:.1f} dB"
+    assert psnr(g2, o2) >= floor - 1.0
+    assert abs(psnr(g1, g2) - floor) <= 1.5, f"GPU seed vs seed {psnr(g1, g2):.1f} dB, reference seed vs seed {floor:.1f} dB"
+
+
+def test_reflected_soft_shadows_have_the_reference_mean_and_variance(textures_dir):
+    """Without -gr the reference traces gr_samples identical reflection rays, but each of their hits draws its own
+    ss_samples shadow samples and is clamped on its own: a reflected penumbra is an average of gr_samples estimates.
+    On the pixels of a fully lit mirror wall that show the penumbra only through the reflection, the per-pixel variance
+    over many seeds must be the restatement's (tracing one reflection ray and re-using its colour gr_samples times
+    would make it gr_samples times larger), and the mean image must agree."""
+    n = cases.MIRROR_SEEDS
+    imgs, st = render_seeds("mirror", cases.MIRROR_FLAGS, range(100, 100 + n), textures_dir)
+    x = imgs.astype(np.float64)
+    mean, var = x.mean(axis=0), x.var(axis=0).sum(axis=2)
+    direct, _ = render_seeds("mirror", cases.MIRROR_DIRECT_FLAGS, range(100, 100 + n), textures_dir)
+    direct_var = direct.astype(np.float64).var(axis=0).sum(axis=2)
+    o_direct, o_mean, o_var = SEEDED["mirror_direct_var"], SEEDED["mirror_mean"], SEEDED["mirror_var"]
+    mask = (o_direct == 0) & (direct_var == 0) & (o_var > 0)
+    assert mask.sum() >= 100
+    ratio = var[mask].sum() / o_var[mask].sum()
+    assert 0.6 <= ratio <= 1.6, f"variance of the reflected penumbra: {ratio:.2f} x the reference's"
+    assert psnr(mean, o_mean) >= 40.0
+    assert np.abs(mean - o_mean)[mask].mean() <= 3.0
+    # every reflection ray is counted as the reference traces it
+    _, ost = oracle.render(cases.SCENES["mirror"](), cases.MIRROR_FLAGS, textures_dir)
+    assert (st.shadow_rays_ref, st.reflection_rays_ref, st.refraction_rays_ref) == (ost.shadow, ost.reflection, ost.refraction)
+    assert st.reflection_rays == ost.reflection          # depth 1: all gr_samples rays are traced for real
+
+
+@pytest.mark.parametrize("scene,flags", [("ref120", ["-ss", "-sss", "16"]), ("ref120", ["-r", "-ss", "-sss", "16"]),
+                                         ("ref120", ["-rd", "3", "-grs", "2", "-ss", "-sss", "5"]), ("glass", ["-rd", "2", "-grs", "1", "-ss", "-sss", "4", "-u"]),
+                                         ("bvh5", ["-r", "-grs", "3", "-ss", "-sss", "8"])])
+def test_soft_shadow_ray_counts_equal_the_reference(scene, flags, textures_dir):
+    """How many shadow / reflection / refraction rays a soft-shadow render traces does not depend on the random numbers
+    (a sample ray is traced whatever it hits), so the reference-equivalent counts are exact here too."""
+    text = cases.SCENES[scene]()
+    _, st = api.render_scene_text(text, flags, textures_dir)
+    _, ost = oracle.render(text, flags, textures_dir)
+    assert st.primary_rays == ost.primary
+    assert (st.shadow_rays_ref, st.reflection_rays_ref, st.refraction_rays_ref) == (ost.shadow, ost.reflection, ost.refraction)
+
+
+@pytest.mark.parametrize("scene,flags", cases.STOCHASTIC_BANDED, ids=[cases.case_id(s, f) for s, f in cases.STOCHASTIC_BANDED])
+def test_all_effects_on_a_crowded_scene_match_the_restatements_high_sample_render(scene, flags, textures_dir):
+    """2000 random primitives (a fifth of them moving inside second-level hierarchies, some transparent) with motion blur,
+    soft shadows, reflection and refraction at 64 x 64 samples per pixel.  The high-sample image is the CPU restatement's,
+    rendered in bands (tests/golden/make_seeded.py): the reference binary would need hours for this frame."""
+    img, st = api.render_scene_text(cases.SCENES[scene](), flags, textures_dir)
+    gold = SEEDED[f"banded_{cases.case_id(scene, flags)}"]
+    p = psnr(img, gold)
+    assert p >= 40.0, f"PSNR {p:.1f} dB"
+    assert st.reflection_rays > 0 and st.refraction_rays > 0 and st.shadow_rays > 0

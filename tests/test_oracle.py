@@ -126,3 +126,20 @@ def test_primitive_known_answers_live():
     import subprocess
     raw = subprocess.run([str(cases.ROOT / "oracle" / "_ref" / "ref_kat"), "400"], capture_output=True, check=True).stdout
     _check_kat(np.frombuffer(raw, dtype=np.float32))
+
+
+def test_seeded_fixtures_are_what_the_restatement_renders(textures_dir):
+    """tests/golden/seeded.npz (made by tests/golden/make_seeded.py): the second-seed image of a noise-floor case and
+    the per-pixel statistics of the mirror scene over cases.MIRROR_SEEDS seeds are reproducible from the restatement."""
+    import sys
+    sys.path.insert(0, str(cases.GOLDEN))
+    import make_seeded
+    seeded = np.load(cases.GOLDEN / "seeded.npz")
+    scene, flags = cases.NOISE_FLOOR[1]
+    img, _ = oracle.render(cases.SCENES[scene](), flags, textures_dir, rand_seed=2)
+    assert np.array_equal(img, seeded[f"floor_{cases.case_id(scene, flags)}_seed2"].astype(np.int32))
+    direct_var, mean, var = make_seeded.mirror_stats()
+    assert np.array_equal(direct_var, seeded["mirror_direct_var"]) and np.array_equal(mean, seeded["mirror_mean"])
+    assert np.array_equal(var, seeded["mirror_var"])
+    mask = (direct_var == 0) & (var > 0)
+    assert mask.sum() >= 100                               # pixels that see a penumbra only through the reflection

@@ -33,7 +33,7 @@ for f in find("trace/**/*kernel_stats.csv"):
 
 traffic = {}
 print("\n== counters (sum over dispatches of each kernel; per-dispatch average in brackets) ==")
-for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_l2"):
     for f in find(f"{d}/**/*counter_collection.csv"):
         agg = defaultdict(lambda: defaultdict(float)); calls = defaultdict(set)
         for row in csv.DictReader(open(f)):
@@ -50,15 +50,20 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
 import json
 out = {}
 for k, c in traffic.items():
+    rec = dict(c)
     if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
         rd = 2.0 * 1024.0 * c.get("FETCH_SIZE", 0.0); wr = 1024.0 * c.get("WRITE_SIZE", 0.0)
-        out[k] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
-# the form bench.py reads as profiles/traffic_latest.json (workload: argv[2], default config2)
-wrapped = {"workload": sys.argv[2] if len(sys.argv) > 2 else "config2",
-           "source": "tools/profile.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled for gfx950, "
-                     "both x1024; one frame at a time, library options overlap=0,graphs=0)",
-           "kernels": out}
-json.dump(wrapped, open(f"{root}/traffic.json", "w"), indent=1)
-print("\n== HBM bytes per launch (FETCH_SIZE x2 x1024 + WRITE_SIZE x1024) ==")
+        rec.update(read_bytes_per_launch=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr)
+    out[k] = rec
+# the form bench.py reads as profiles/counters_latest.json: {workload: {"source": ..., "kernels": {kernel: per-launch averages}}}
+workload = sys.argv[2] if len(sys.argv) > 2 else "config2"
+wrapped = {workload: {"source": "tools/profile.sh (rocprofv3 --pmc, one counter group per pass; FETCH_SIZE doubled for gfx950, FETCH_SIZE and "
+                                "WRITE_SIZE x1024; one frame at a time, library options overlap=0,graphs=0); values are averages per launch",
+                      "kernels": out}}
+json.dump(wrapped, open(f"{root}/counters.json", "w"), indent=1)
+print("\n== HBM bytes per launch (FETCH_SIZE x2 x1024 + WRITE_SIZE x1024), L2 hit rate, vector instructions ==")
 for k, v in out.items():
-    print(f"{k:24s} read {v['read_bytes_per_launch']/1e6:10.3f} MB  write {v['write_bytes_per_launch']/1e6:10.3f} MB")
+    hit = v.get("TCC_HIT_sum"); miss = v.get("TCC_MISS_sum")
+    l2 = f"{hit / (hit + miss):7.1%}" if hit is not None and miss is not None and hit + miss > 0 else "    n/a"
+    print(f"{k:24s} read {v.get('read_bytes_per_launch', 0)/1e6:10.3f} MB  write {v.get('write_bytes_per_launch', 0)/1e6:10.3f} MB  L2 hit {l2}  "
+          f"VALU insts {v.get('SQ_INSTS_VALU', 0):.4g}  wait_any/wave_cycles {v.get('SQ_WAIT_ANY', 0) / max(1.0, v.get('SQ_WAVE_CYCLES', 0)):.2f}")
