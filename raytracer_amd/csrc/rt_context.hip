@@ -216,6 +216,7 @@ struct rt_ctx {
     bool count_rays = true;                  // frames with statistics count rays (off: stage times only, at the speed of plain frames)
     // 0 = chosen per launch (see enqueue_frame)
     int grid_primary = 0, grid_secondary = 0, grid_shadow = 0, grid_shade = 0;
+    bool bundle_reflections = true;          // ... as one traced ray with gr_samples hit records (off: gr_samples traced rays)
     bool replicate_reflections = true;       // soft shadows: first reflections traced gr_samples times, each with its own shadow samples
     bool fast_samples = true;                // soft-shadow sample rays: hardware reciprocals instead of IEEE division
     int lds_prims = 1;                       // tiny scenes: primitive records in LDS; 1 = shadow kernel only, 2 = extend too
@@ -371,6 +372,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "skip_unlit") == 0) { c->skip_unlit = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "count_rays") == 0) { c->count_rays = value != 0; return RT_OK; }
     if (std::strcmp(name, "fast_samples") == 0) { c->fast_samples = value != 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "bundle_reflections") == 0) { c->bundle_reflections = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "replicate_reflections") == 0) { c->replicate_reflections = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "overlap") == 0) { c->overlap = value != 0; c->drop_graphs(); return RT_OK; }
     return c->fail(RT_ERR_ARG, "unknown option %s", name);
@@ -1011,7 +1013,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     const int MB = cfg->motion_blur ? cfg->mb_samples : 1;
     if (AA < 1 || DOF < 1 || MB < 1) return c->fail(RT_ERR_ARG, "sample counts must be >= 1");
     if ((long long)AA * DOF * MB > (1ll << 30)) return c->fail(RT_ERR_ARG, "too many samples per pixel");
-    if (cfg->gr_samples < 1 || cfg->gr_samples >= (1 << 30)) return c->fail(RT_ERR_ARG, "gr_samples must be >= 1");
+    if (cfg->gr_samples < 1 || cfg->gr_samples >= (1 << 29)) return c->fail(RT_ERR_ARG, "gr_samples must be in 1 .. 2^29 - 1");
     if (cfg->soft_shadows && cfg->ss_samples < 1) return c->fail(RT_ERR_ARG, "ss_samples must be >= 1");
     const int D = cfg->reflect_refract_depth < 0 ? 0 : cfg->reflect_refract_depth;
     if (D > RT_MAX_LEVELS - 4) return c->fail(RT_ERR_ARG, "reflect depth above %d", RT_MAX_LEVELS - 4);
@@ -1032,6 +1034,8 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     f.fallback_full = (fb == 1);
     f.light_radius = cfg->light_radius; f.seed = cfg->seed; f.fast_samples = c->fast_samples ? 1 : 0; f.count_stats = count_stats ? 1 : 0; f.skip_unlit = c->skip_unlit ? 1 : 0;
     f.replicate = (cfg->soft_shadows && c->replicate_reflections) ? 1 : 0;
+    // identical reflection rays are traced once and recorded gr_samples times (the packed hit record holds 12-bit copy numbers)
+    f.bundle = (f.replicate && !cfg->glossy_reflect && cfg->gr_samples <= 4096 && c->bundle_reflections) ? 1 : 0;
     f.tiles_x = c->tiles_x; f.tiles_y = c->tiles_y; f.n_local_tiles = (int)c->local_tiles.size(); f.local_tiles = c->d_local_tiles.p;
 
     const long long n_slots = (long long)c->local_tiles.size() * RT_TILE_PIX;

@@ -770,6 +770,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
         bool active = PRIMARY ? i < f.pix_count : i >= 0;
         Ray r; uint32_t path = 0, mult = 1; int slot = 0;
         bool replicated = false;            // an ancestor's reflection was already traced gr_samples times (soft shadows)
+        int copies = 1;                     // hits this ray records when it hits: it stands for a bundle of identical rays (f.bundle)
         r.o = mk(0, 0, 0); r.d = mk(0, 0, 1); r.time = 0.0f;
         if (active) {
             if (PRIMARY) active = generate_primary(f, i, r, path, slot);
@@ -777,6 +778,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
                 float4 a = qa_next, b = qb_next;
                 r.o = mk(a.x, a.y, a.z); r.d = mk(a.w, b.x, b.y); r.time = 0.0f;   // secondary rays carry time 0 (ray.h:13)
                 path = (uint32_t)f2i(b.z); mult = (uint32_t)f2i(b.w) & 0x7fffffffu; replicated = (f2i(b.w) >> 31) & 1;
+                if (f.bundle && replicated) copies = f.gr_samples;
             }
         }
         if (!PRIMARY && g + (int)gridDim.x < n_chunks) {
@@ -787,10 +789,10 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
         Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
         bool hit = active && trace<false, SUB>(sc, f, s_nodes, s_leaves, s_stack, r, !PRIMARY && f.fallback_full, best);
 
-        int n_children = 0, n_reflect = 0; bool refract = false;
+        int n_children = 0, n_reflect = 0, n_entries = 0; bool refract = false;   // n_reflect: child colours summed at resolve; n_entries: rays queued for them
         HitOut h; V3 N = mk(0, 0, 1), rd = mk(0, 0, 1), fd = mk(0, 0, 1); float weight = 0.0f, gloss_angle = 0.0f; bool glossy = false;
         if (hit) {
-            if (STATS) n_shadow_ref += shadow_per_hit * mult;
+            if (STATS) n_shadow_ref += shadow_per_hit * mult * (unsigned)copies;
             full_hit(sc, f, r, best, h);
             if (spawn) {
                 float4 m0 = sc.mats[3 * h.gid], m1 = sc.mats[3 * h.gid + 1], m2 = sc.mats[3 * h.gid + 2];
@@ -812,7 +814,11 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
                     // reflection of a path is therefore traced gr_samples times for real (distinct path ids, so distinct
                     // sample sets); below it, where a contribution carries reflectivity^2 or less, identical rays are
                     // traced once again (the reference would trace gr_samples^depth of them).
+                    // f.bundle: the gr_samples rays are geometrically identical, so ONE queue entry is traced and its hit is
+                    // recorded gr_samples times (a bundle of consecutive hit records with their own path ids, hence their own
+                    // shadow samples); everything below a bundle stays a bundle of the same size, copy s under copy s.
                     n_reflect = (glossy || (f.replicate && !replicated)) ? f.gr_samples : 1;
+                    n_entries = (f.bundle && !glossy) ? 1 : n_reflect;
                 }
                 if (transparency > 0) {                                  // raytracer.cpp:444-497
                     float n1 = 1.0f, n2 = ior;
@@ -833,7 +839,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
                         weight = transparency * (1.0f - fresnel);
                     }
                 }
-                n_children = n_reflect + (refract ? 1 : 0);
+                n_children = n_entries + (refract ? 1 : 0);
             }
         }
 
@@ -845,36 +851,47 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
             int incl = n_children;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) { int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
-            const int total_children = __shfl(incl, 63, 64), total_hits = __popcll(hm);
+            const int total_children = __shfl(incl, 63, 64);
+            int total_hits = __popcll(hm), before = __popcll(hm & ((1ull << lane) - 1ull));
+            if (!PRIMARY && f.bundle) {                                   // hits of bundles take `copies` records each
+                int inc2 = hit ? copies : 0;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { int v = __shfl_up(inc2, off, 64); if (lane >= off) inc2 += v; }
+                total_hits = __shfl(inc2, 63, 64); before = inc2 - (hit ? copies : 0);
+            }
             unsigned long long pair = 0;
             if (lane == 0 && (total_hits | total_children))
                 pair = atomicAdd((unsigned long long*)&w.ctr[RT_CTR_NODE(level, rg)],
                                  ((unsigned long long)(unsigned)total_children << 32) | (unsigned long long)(unsigned)total_hits);
             const int base_node = __shfl((int)(unsigned)(pair & 0xffffffffull), 0, 64), base_link = __shfl((int)(unsigned)(pair >> 32), 0, 64);
-            if (hit) node = base_node + __popcll(hm & ((1ull << lane) - 1ull));
+            if (hit) node = base_node + before;
             qslot = base_link + incl - n_children;
         }
-        if (hit && node >= node_cap) { w.stats[RT_S_ERR] = 1; hit = false; }
+        if (hit && node + copies > node_cap) { w.stats[RT_S_ERR] = 1; hit = false; }
         node = hit ? node_base + rg * node_cap + node : -1;
         if (!PRIMARY && active) w.link[link_in + i] = node;
         if (hit) {
-            w.n_a[node] = make_float4(h.p.x, h.p.y, h.p.z, r.time);
-            w.n_b[node] = make_float4(h.n.x, h.n.y, h.n.z, i2f(h.gid));
-            if (f.textures) w.n_uv[node] = make_float2(h.u, h.v);
-            if (PRIMARY) w.n_pix[node] = slot;
             if (n_children > 0 && qslot + n_children > link_cap) {
-                w.stats[RT_S_ERR] = 1; n_children = 0; n_reflect = 0; refract = false;
+                w.stats[RT_S_ERR] = 1; n_children = 0; n_reflect = 0; n_entries = 0; refract = false;
             }
             qslot += rg * link_cap;                                      // the region's part of the next level's queue
             const int first_link = link_out + qslot;
-            w.n_c[node] = make_float4(i2f(n_children ? first_link : -1), weight, i2f((int)path),
-                                      i2f(n_reflect | (refract ? (1 << 30) : 0)));
+            // one record per copy of the bundle: same hit, own path id (own shadow samples), own place under the parent
+            for (int cp = 0; cp < copies; ++cp) {
+                const uint32_t cpath_self = cp ? mix32(path + 0x9E3779B1u * (uint32_t)cp) : path;
+                w.n_a[node + cp] = make_float4(h.p.x, h.p.y, h.p.z, r.time);
+                w.n_b[node + cp] = make_float4(h.n.x, h.n.y, h.n.z, i2f(h.gid));
+                if (f.textures) w.n_uv[node + cp] = make_float2(h.u, h.v);
+                const int packed = f.bundle ? (n_reflect | (cp << 13) | (1 << 29) | (refract ? (1 << 30) : 0)) : (n_reflect | (refract ? (1 << 30) : 0));
+                w.n_c[node + cp] = make_float4(i2f(n_children ? first_link : -1), weight, i2f((int)cpath_self), i2f(packed));
+            }
+            if (PRIMARY) w.n_pix[node] = slot;
             const float EPS = 1e-4f;
             // multiplicity of the children: each of the reference's gr_samples copies of a deduplicated ray
             unsigned long long cm = (unsigned long long)mult * (unsigned)(n_reflect == 1 ? f.gr_samples : 1);
             const uint32_t flag_refl = (replicated || (f.replicate && !glossy)) ? 0x80000000u : 0u;
             const uint32_t child_mult = (cm > 0x7fffffffull ? 0x7fffffffu : (uint32_t)cm) | flag_refl;
-            for (int j = 0; j < n_reflect; ++j) {                        // raytracer.cpp:415-421
+            for (int j = 0; j < n_entries; ++j) {                        // raytracer.cpp:415-421
                 V3 dir = rd;
                 uint32_t cpath = mix32(path * 0x9E3779B1u + (uint32_t)j + 1u);
                 if (glossy) {
@@ -888,13 +905,13 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
             if (refract) {                                               // raytracer.cpp:474-479
                 V3 org = h.p + fd * EPS;
                 uint32_t cpath = mix32(path * 0x9E3779B1u + 0x7FFFFFFFu);
-                qa_out[qslot + n_reflect] = make_float4(org.x, org.y, org.z, fd.x);
-                qb_out[qslot + n_reflect] = make_float4(fd.y, fd.z, i2f((int)cpath), i2f((int)(mult | (replicated ? 0x80000000u : 0u))));
-                if (STATS) { ++n_refr; n_refr_ref += mult; }
+                qa_out[qslot + n_entries] = make_float4(org.x, org.y, org.z, fd.x);
+                qb_out[qslot + n_entries] = make_float4(fd.y, fd.z, i2f((int)cpath), i2f((int)(mult | (replicated ? 0x80000000u : 0u))));
+                if (STATS) { ++n_refr; n_refr_ref += (unsigned long long)mult * (unsigned)copies; }
             }
             if (STATS) {
-                n_refl += (unsigned)n_reflect;
-                if (n_reflect) n_refl_ref += (unsigned long long)mult * (unsigned)f.gr_samples;
+                n_refl += (unsigned)n_entries;
+                if (n_reflect) n_refl_ref += (unsigned long long)mult * (unsigned)copies * (unsigned)f.gr_samples;
             }
         }
     }
@@ -1120,15 +1137,26 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, Dev
 
         if (level < f.max_depth) {                                       // raytracer.cpp:369-503
             const int first = f2i(c.x), packed = f2i(c.w);
-            const int n_reflect = packed & 0x3fffffff;
+            // bundle: this hit is copy `cp` of a bundle of identical hits; a child ray was traced once and recorded as a
+            // bundle of consecutive hits (link = its first one), copy cp of the child under copy cp of the parent
+            const bool bundle = (packed >> 29) & 1;
+            const int n_reflect = bundle ? (packed & 0x1fff) : (packed & 0x1fffffff);
+            const int cp = bundle ? ((packed >> 13) & 0xffff) : 0;
             const bool refract = (packed >> 30) & 1;
             const float reflectivity = m2.z;
             V3 rc = mk(0.0f, 0.0f, 0.0f);
             if (n_reflect == 1) {
                 int ch = w.link[first];
+                if (bundle && ch >= 0) ch += cp;
                 V3 cc = mk(0.0f, 0.0f, 0.0f);
                 if (ch >= 0) { float4 q = w.n_col[ch]; cc = mk(q.x, q.y, q.z); }
                 for (int s = 0; s < f.gr_samples; ++s) rc = rc + cc;     // the gr_samples identical rays of raytracer.cpp:400-432
+            } else if (bundle) {
+                const int base = n_reflect ? w.link[first] : -1;         // n_reflect consecutive hits of one traced ray
+                for (int s = 0; s < n_reflect; ++s) {
+                    if (base >= 0) { float4 q = w.n_col[base + cp * n_reflect + s]; rc = rc + mk(q.x, q.y, q.z); }
+                    else rc = rc + mk(0.0f, 0.0f, 0.0f);
+                }
             } else {
                 for (int s = 0; s < n_reflect; ++s) {
                     int ch = w.link[first + s];
@@ -1141,7 +1169,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, Dev
             rc = rc * reflectivity;
             col = col + rc;
             if (refract) {                                               // raytracer.cpp:494-497
-                int ch = w.link[first + n_reflect];
+                int ch = w.link[first + (bundle ? (n_reflect ? 1 : 0) : n_reflect)];
+                if (bundle && ch >= 0) ch += cp;
                 V3 fc = mk(0.0f, 0.0f, 0.0f);
                 if (ch >= 0) { float4 q = w.n_col[ch]; fc = mk(q.x, q.y, q.z); }
                 col = col + fc * c.y;

@@ -84,6 +84,7 @@ struct DevFrame {
     int fast_samples;              // randomly drawn shadow rays use reciprocal arithmetic (distribution-level parity)
     int skip_unlit;                // shadow rays of (hit, light) pairs whose N.L is clearly negative are not traced
     int replicate;                 // soft shadows: the first reflection of a path is traced gr_samples times (see k_extend)
+    int bundle;                    // ... as ONE traced ray whose hit is recorded gr_samples times (replicate, no glossy perturbation)
     int count_stats;               // kernels add their ray counts to DevWork::stats (one atomic per workgroup and counter)
     // sharding
     int tiles_x, tiles_y, n_local_tiles;
@@ -98,7 +99,8 @@ struct DevFrame {
 // ---- work buffers ---------------------------------------------------------------------------------------
 // Hit-tree node (one per shaded hit), structure of arrays:
 //   n_a = (hit point xyz, hit time)           n_b = (geometric normal xyz, bits gid)
-//   n_c = (bits first_link | -1, refraction weight, bits path id, bits n_reflection_children | has_refraction << 30)
+//   n_c = (bits first_link | -1, refraction weight, bits path id, bits n_reflection_children | has_refraction << 30), or, for a hit
+//         that is copy cp of a bundle: bits n_reflection_children (13) | cp << 13 | 1 << 29 | has_refraction << 30
 //   n_uv = (u, v) when texture mapping is on   n_col = resolved colour (r, g, b, 0)
 //   n_pix (level 0 only) = local pixel slot.
 // Every level's part of the node arena and of the ray queue is cut into `regions` (<= RT_REGIONS) regions of equal capacity, each

@@ -95,7 +95,18 @@ def test_reflected_soft_shadows_have_the_reference_mean_and_variance(textures_di
     # every reflection ray is counted as the reference traces it
     _, ost = oracle.render(cases.SCENES["mirror"](), cases.MIRROR_FLAGS, textures_dir)
     assert (st.shadow_rays_ref, st.reflection_rays_ref, st.refraction_rays_ref) == (ost.shadow, ost.reflection, ost.refraction)
-    assert st.reflection_rays == ost.reflection          # depth 1: all gr_samples rays are traced for real
+    # the gr_samples identical rays are traced as one ray whose hit is recorded gr_samples times, each with its own samples
+    assert st.reflection_rays * 16 == ost.reflection
+    # ... which is the same picture, statistically, as tracing every one of them
+    sep, st2 = render_seeds("mirror", cases.MIRROR_FLAGS, range(100, 100 + n), textures_dir, {"bundle_reflections": 0})
+    y = sep.astype(np.float64)
+    assert st2.reflection_rays == ost.reflection and st2.shadow_rays == st.shadow_rays and st2.nodes_shaded == st.nodes_shaded
+    r2 = y.var(axis=0).sum(axis=2)[mask].sum() / o_var[mask].sum()
+    assert 0.6 <= r2 <= 1.6 and psnr(y.mean(axis=0), mean) >= 40.0
+    # and tracing the reflection once with ONE set of shadow samples (replicate_reflections = 0) is what it must not be
+    one, _ = render_seeds("mirror", cases.MIRROR_FLAGS, range(100, 100 + n), textures_dir, {"replicate_reflections": 0})
+    r1 = one.astype(np.float64).var(axis=0).sum(axis=2)[mask].sum() / o_var[mask].sum()
+    assert r1 > 3.0, f"variance ratio without replication {r1:.2f}"
 
 
 @pytest.mark.parametrize("scene,flags", [("ref120", ["-ss", "-sss", "16"]), ("ref120", ["-r", "-ss", "-sss", "16"]),
