@@ -43,7 +43,7 @@ WORKLOADS = {
     "config4s": dict(scene="ref", res=(3840, 2160), flags=["-aa", "-aas", "4", "-gr", "-grs", "16", "-dof", "-dofs", "4", "-m", "-mbs", "4"]),
     # the all-effects configuration, synthetic part: 10M random primitives (seed 43), 4K, every effect on at a reduced sample count
     "config5s": dict(scene="random", n=10_000_000, seed=43, res=(3840, 2160),
-                     flags=["-aa", "-aas", "2", "-dof", "-dofs", "2", "-m", "-mbs", "2", "-t", "-ss", "-sss", "16", "-r", "-rd", "2", "-gr", "-grs", "4"]),
+                     flags=["-aa", "-aas", "2", "-dof", "-dofs", "2", "-m", "-mbs", "2", "-t", "-ss", "-sss", "4", "-r", "-gr", "-grs", "2"]),
 }
 HBM_PEAK_GBS = 8000.0
 # FP32 vector peak of the chip: 1024 SIMDs x one 64-lane instruction per 2 cycles x 2.4 GHz x 2 flop (an FMA) per lane
@@ -263,7 +263,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     # Four by default: one per hardware queue of the process (more share queues and lose again).  Not used for frames
     # of many samples per pixel, which keep the GPU busy on their own.
     spp = cfg.samples_per_pixel()
-    P = max(1, frames_in_flight) if spp < 16 else 1
+    P = max(1, frames_in_flight) if (spp < 16 and W * H <= 1920 * 1080) else 1
     if world > 1:
         P = min(P, 3)                                 # the communicator's stream takes the fourth hardware queue
 
@@ -329,9 +329,26 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
 
     # Ray counts (identical every frame: the generator is counter based) and per-kernel device times.  The profiled
     # frame is enqueued behind four ordinary ones so that the GPU, not the host, paces it.
+    def note(msg):
+        if rank == 0:
+            print(f"[bench {name}] {msg}", file=sys.stderr, flush=True)
+
+    note(f"scene uploaded in {upload_s:.2f} s")
     st = r.render_device(cfg, block.data_ptr(), want_stats=True)     # ray counts (the counting kernel variants)
+    heavy = st.ms_total > 150.0                                      # a frame of hundreds of ms: no extra frames beyond the timed ones
+    note(f"first frame {st.ms_total:.1f} ms, {st.total_rays()} rays, {st.batches} batches")
     shadow_all = None
-    if detail:
+    if heavy:
+        steps = min(steps, 3); warmup = min(warmup, 1)
+    if detail and heavy:
+        r.set_option("count_rays", 0)
+        tm = r.render_device(cfg, block.data_ptr(), want_stats=True)
+        r.set_option("count_rays", 1)
+        for field in ("ms_extend_primary", "ms_extend_secondary", "ms_shadow", "ms_shade", "ms_other", "ms_total",
+                      "launches_extend_primary", "launches_extend_secondary", "launches_shadow", "launches_shade"):
+            setattr(st, field, getattr(tm, field))
+        note(f"stage times: {tm.ms_total:.1f} ms")
+    elif detail:
         r.set_option("skip_unlit", 0)                                # how many shadow rays the N.L <= 0 rule leaves untraced
         shadow_all = r.render_device(cfg, block.data_ptr(), want_stats=True).shadow_rays
         r.set_option("skip_unlit", 1)
@@ -354,7 +371,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
 
     # latency of one frame alone (enqueue -> done), next to the throughput the timed loop measures
     torch.cuda.synchronize(dev)
-    n_lat = 10 if spp < 16 else 2
+    n_lat = 1 if heavy else (10 if spp < 16 else 2)
     r.render_device(cfg, block.data_ptr()); r.synchronize()
     t_lat = time.perf_counter()
     for _ in range(n_lat):
@@ -362,7 +379,8 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     frame_latency_ms = (time.perf_counter() - t_lat) * 1000.0 / n_lat
     # every context records a frame graph on its second frame with the same output buffer; a pipeline alternates
     # between two blocks, so it needs four frames before both graphs exist
-    warm_steps = max(warmup, (4 if pipelined else 2) * P)
+    warm_steps = warmup if heavy else max(warmup, (4 if pipelined else 2) * P)
+    note(f"one frame alone {frame_latency_ms:.2f} ms; warming up ({warm_steps}) and timing {steps} steps")
     for _ in range(warm_steps):
         step()
     if world > 1:

@@ -257,6 +257,29 @@ int rt_synchronize(rt_ctx* ctx);
 
 const char* rt_last_error(const rt_ctx* ctx);   /* ctx may be NULL: error of the last failed rt_create */
 
+/* ---- several GPUs of one node, one process (no counterpart in the reference, which is single-threaded) ------------
+ * The render loop of raytracer.cpp:109-193 split over n devices: device k renders the 32x32 tiles with
+ * (tile_x + tile_y) % n == k, the tile blocks are gathered to the first device of the list with RCCL (one group of
+ * ncclRecv / ncclSend over xGMI per frame; librccl is loaded at run time, only by rt_multi_create) and re-ordered there
+ * into the row-major frame.  The frame is bit-identical to the single-device one for any n.  A device id may appear more
+ * than once (rehearsal on a machine with fewer GPUs): RCCL cannot span duplicates, the blocks then travel by
+ * hipMemcpyAsync.  Calls on one rt_multi must be serialised by the caller. */
+typedef struct rt_multi rt_multi;
+rt_multi* rt_multi_create(int32_t n_devices, const int32_t* device_ids, uint64_t workspace_bytes_per_device);
+void rt_multi_destroy(rt_multi* m);
+int rt_multi_set_option(rt_multi* m, const char* name, int64_t value);             /* rt_set_option on every context */
+/* rt_upload_scene + rt_upload_bvh on every device (nodes == NULL: no BVH), one host thread per device. */
+int rt_multi_upload(rt_multi* m, const rt_scene* scene, const rt_bvh_node* nodes, int32_t n_nodes, const int32_t* prim_ids, int32_t n_prim_ids);
+/* One frame: rgb_out (host) receives res_y*res_x*3 bytes as rt_render writes them.  rt_multi_render_device only
+ * enqueues; the frame is in rt_multi_image() (memory of the first device) after rt_multi_synchronize(). */
+int rt_multi_render(rt_multi* m, const rt_config* cfg, uint8_t* rgb_out);
+int rt_multi_render_device(rt_multi* m, const rt_config* cfg);
+int rt_multi_synchronize(rt_multi* m);
+void* rt_multi_image(rt_multi* m);
+rt_ctx* rt_multi_context(rt_multi* m, int32_t rank);        /* the context of device `rank` of the list (statistics, options) */
+int32_t rt_multi_uses_rccl(const rt_multi* m);               /* 1 = blocks gathered with RCCL, 0 = device copies (duplicate ids) */
+const char* rt_multi_last_error(const rt_multi* m);          /* m may be NULL: error of the last failed rt_multi_create */
+
 #ifdef __cplusplus
 }
 #endif

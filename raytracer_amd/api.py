@@ -112,7 +112,9 @@ class HostBvh(C.Structure):
 # every symbol the two headers declare
 API_SYMBOLS = ["rt_default_config", "rt_create", "rt_destroy", "rt_set_stream", "rt_get_stream", "rt_set_option", "rt_upload_scene", "rt_upload_bvh",
                "rt_set_shard", "rt_local_tiles", "rt_max_tiles_per_rank", "rt_render", "rt_render_device",
-               "rt_assemble_tiles", "rt_synchronize", "rt_last_error", "rt_render_device_noalloc", "rt_noalloc_capacity"]
+               "rt_assemble_tiles", "rt_synchronize", "rt_last_error", "rt_render_device_noalloc", "rt_noalloc_capacity",
+               "rt_multi_create", "rt_multi_destroy", "rt_multi_set_option", "rt_multi_upload", "rt_multi_render", "rt_multi_render_device",
+               "rt_multi_synchronize", "rt_multi_image", "rt_multi_context", "rt_multi_uses_rccl", "rt_multi_last_error"]
 HOST_SYMBOLS = ["rt_host_parse_args", "rt_host_parse_scene", "rt_host_load_scene", "rt_host_free_scene",
                 "rt_host_build_bvh", "rt_host_free_bvh", "rt_host_read_ppm", "rt_host_write_ppm", "rt_host_write_ppm_binary", "rt_host_free",
                 "rt_host_camera_ray"]
@@ -144,6 +146,17 @@ def lib():
     L.rt_assemble_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.rt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(Config), C.c_void_p]
     L.rt_noalloc_capacity.argtypes = []; L.rt_noalloc_capacity.restype = C.c_uint64
+    L.rt_multi_create.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.c_uint64]; L.rt_multi_create.restype = C.c_void_p
+    L.rt_multi_destroy.argtypes = [C.c_void_p]; L.rt_multi_destroy.restype = None
+    L.rt_multi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.rt_multi_upload.argtypes = [C.c_void_p, C.POINTER(Scene), C.POINTER(BvhNode), C.c_int32, C.POINTER(C.c_int32), C.c_int32]
+    L.rt_multi_render.argtypes = [C.c_void_p, C.POINTER(Config), C.c_void_p]
+    L.rt_multi_render_device.argtypes = [C.c_void_p, C.POINTER(Config)]
+    L.rt_multi_synchronize.argtypes = [C.c_void_p]
+    L.rt_multi_image.argtypes = [C.c_void_p]; L.rt_multi_image.restype = C.c_void_p
+    L.rt_multi_context.argtypes = [C.c_void_p, C.c_int32]; L.rt_multi_context.restype = C.c_void_p
+    L.rt_multi_uses_rccl.argtypes = [C.c_void_p]; L.rt_multi_uses_rccl.restype = C.c_int32
+    L.rt_multi_last_error.argtypes = [C.c_void_p]; L.rt_multi_last_error.restype = C.c_char_p
     L.rt_synchronize.argtypes = [C.c_void_p]
     L.rt_last_error.argtypes = [C.c_void_p]; L.rt_last_error.restype = C.c_char_p
     L.rt_host_parse_args.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(Config), C.c_char_p, C.c_int]
@@ -500,6 +513,60 @@ class Renderer:
     def close(self):
         if self._ctx:
             lib().rt_destroy(self._ctx); self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiRenderer:
+    """rt_multi: several GPUs of one node driven by this process (a device id may repeat for rehearsals)."""
+
+    def __init__(self, devices: list[int], workspace_bytes: int = 0):
+        arr = (C.c_int32 * len(devices))(*devices)
+        self._m = lib().rt_multi_create(len(devices), arr, workspace_bytes)
+        if not self._m:
+            raise RtError(-2, lib().rt_multi_last_error(None).decode())
+        self.n = len(devices); self.width = self.height = 0
+
+    def _check(self, rc: int):
+        if rc != RT_OK:
+            raise RtError(rc, lib().rt_multi_last_error(self._m).decode())
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(lib().rt_multi_uses_rccl(self._m))
+
+    def set_option(self, name: str, value: int):
+        self._check(lib().rt_multi_set_option(self._m, name.encode(), value))
+
+    def upload(self, ls: LoadedScene, with_bvh: bool = True):
+        if with_bvh:
+            b = ls.bvh()
+            self._check(lib().rt_multi_upload(self._m, C.byref(ls.scene), b.nodes, b.n_nodes, b.prim_ids, b.n_prim_ids))
+        else:
+            self._check(lib().rt_multi_upload(self._m, C.byref(ls.scene), None, 0, None, 0))
+        self.width, self.height = ls.width, ls.height
+
+    def render(self, cfg: Config) -> np.ndarray:
+        out = np.zeros(self.width * self.height * 3, dtype=np.uint8)
+        self._check(lib().rt_multi_render(self._m, C.byref(cfg), out.ctypes.data_as(C.c_void_p)))
+        return out.reshape(self.height, self.width, 3)
+
+    def render_device(self, cfg: Config):
+        self._check(lib().rt_multi_render_device(self._m, C.byref(cfg)))
+
+    def synchronize(self):
+        self._check(lib().rt_multi_synchronize(self._m))
+
+    def image_ptr(self) -> int:
+        return int(lib().rt_multi_image(self._m) or 0)
+
+    def close(self):
+        if self._m:
+            lib().rt_multi_destroy(self._m); self._m = None
 
     def __del__(self):
         try:

@@ -2,8 +2,9 @@
 // banner and progress lines, scene from ../ASCII/scene.json, textures from ../Textures, image to ../Output.
 // The pixel loop between the two timer reads is one rt_render() call into the HIP pipeline.
 //
-// Extensions (not in the reference): --scene PATH, --textures DIR, --outdir DIR, --gpu N, --seed N, --fallback N,
-// --p6 (binary PPM instead of the reference's text form).
+// Extensions (not in the reference): --scene PATH, --textures DIR, --outdir DIR, --gpu N, --gpus N (the frame split over the
+// first N devices of the node, tile blocks gathered with RCCL), --seed N, --fallback N, --p6 (binary PPM instead of the
+// reference's text form).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -19,7 +20,7 @@ int main(int argc, char* argv[]) {
     char out_name[512];
     rt_host_parse_args(argc, argv, 1, &cfg, out_name, (int)sizeof out_name);
     std::string scene_path = "../ASCII/scene.json", tex_dir = "../Textures", out_dir = "../Output";
-    int gpu = 0;
+    int gpu = 0, gpus = 1;
     bool p6 = false;
     for (int i = 1; i < argc; ++i) if (!std::strcmp(argv[i], "--p6")) p6 = true;
     for (int i = 1; i + 1 < argc; ++i) {
@@ -27,6 +28,7 @@ int main(int argc, char* argv[]) {
         else if (!std::strcmp(argv[i], "--textures")) tex_dir = argv[i + 1];
         else if (!std::strcmp(argv[i], "--outdir")) out_dir = argv[i + 1];
         else if (!std::strcmp(argv[i], "--gpu")) gpu = std::atoi(argv[i + 1]);
+        else if (!std::strcmp(argv[i], "--gpus")) gpus = std::atoi(argv[i + 1]);
     }
 
     // raytracer.cpp:34-49
@@ -42,6 +44,28 @@ int main(int argc, char* argv[]) {
     const rt_scene& sc = hs->scene;
     const int W = (int)sc.camera.res_x, H = (int)sc.camera.res_y;
     std::printf("\n---Raytracing for %d object(s)---\n", sc.n_spheres + sc.n_cubes + sc.n_planes);
+
+    if (gpus > 1) {
+        // one process, several devices: rt_multi_* (tiles interleaved over the devices, blocks gathered to the first one)
+        std::vector<int32_t> ids; for (int i = 0; i < gpus; ++i) ids.push_back(gpu + i);
+        rt_multi* mm = rt_multi_create(gpus, ids.data(), 0);
+        if (!mm) { std::fprintf(stderr, "%s\n", rt_multi_last_error(nullptr)); rt_host_free_scene(hs); return 1; }
+        rt_host_bvh mb{};
+        int mrc = cfg.bvh ? rt_host_build_bvh(&sc, 8, &mb) : RT_OK;
+        std::printf(cfg.bvh ? "Running BVH accelerated RT...\n" : "Running unaccelerated RT...\n");
+        if (mrc == RT_OK) mrc = rt_multi_upload(mm, &sc, cfg.bvh ? mb.nodes : nullptr, mb.n_nodes, mb.prim_ids, mb.n_prim_ids);
+        std::vector<uint8_t> frame((size_t)W * H * 3);
+        auto m0 = std::chrono::system_clock::now();
+        if (mrc == RT_OK) mrc = rt_multi_render(mm, &cfg, frame.data());
+        auto m1 = std::chrono::system_clock::now();
+        if (mrc != RT_OK) { std::fprintf(stderr, "%s\n", rt_multi_last_error(mm)); rt_multi_destroy(mm); rt_host_free_scene(hs); return 1; }
+        for (int p = 10; p <= 90; p += 10) std::printf("%d%% done\n", p);
+        std::printf("Finished! Time taken: %gs\n", (double)((float)std::chrono::duration_cast<std::chrono::milliseconds>(m1 - m0).count() / 1000.0f));
+        std::string mpath = out_dir + "/" + out_name;
+        mrc = p6 ? rt_host_write_ppm_binary(mpath.c_str(), W, H, frame.data()) : rt_host_write_ppm(mpath.c_str(), W, H, 255, frame.data());
+        rt_host_free_bvh(&mb); rt_multi_destroy(mm); rt_host_free_scene(hs);
+        return mrc == RT_OK ? 0 : 1;
+    }
 
     rt_ctx* ctx = rt_create(gpu, 0);
     if (!ctx) { std::fprintf(stderr, "%s\n", rt_last_error(nullptr)); rt_host_free_scene(hs); return 1; }
