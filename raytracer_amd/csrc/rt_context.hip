@@ -940,9 +940,7 @@ static int make_plan(rt_ctx* c, const rt_config* cfg, int D, int L, bool texture
     // (1/64 of the budget covers the rounding of the regions' capacities, see below)
     long long B = (long long)((double)budget * (63.0 / 64.0) / bytes_per);
     B = std::min(B, n_slots);
-    // int32 indexing inside the kernels
-    B = std::min(B, (long long)(2.0e9 / std::max(1.0, nodes_per * std::max(1, L) * (cfg->soft_shadows ? cfg->ss_samples : 1))));
-    for (int attempt = 0; attempt < 12; ++attempt) {
+    for (int attempt = 0; attempt < 40; ++attempt) {
         if (B >= RT_TILE_PIX) B -= B % RT_TILE_PIX; else B -= B % 64;
         if (B < 64) return c->fail(RT_ERR_CAPACITY, "a work area of %llu bytes cannot hold one wavefront of samples at depth %d (up to %.0f hits per sample)",
                                    budget, D, nodes_per);
@@ -968,7 +966,14 @@ static int make_plan(rt_ctx* c, const rt_config* cfg, int D, int L, bool texture
         p.cap_rays = p.fanout ? (size_t)(R * widest_rcap) + 64 : 64;
         p.cap_pix = (size_t)(R * p.rcap[0]);                             // n_pix is indexed by the level-0 node
         p.cap_shadow = p.cap_nodes * (size_t)std::max(L, 1);
-        if (p.cap_nodes > 0x7fffffffull || p.cap_links > 0x7fffffffull) return c->fail(RT_ERR_CAPACITY, "batch too large for 32-bit node indices");
+        // 32-bit indexing inside the kernels: node and link indices, node * lights, and the shadow rays of one region of
+        // one level (k_shadow numbers them inside such a segment)
+        double widest_segment = 0;
+        for (int d = 0; d <= D; ++d) widest_segment = std::max(widest_segment, (double)p.rcap[d] * std::max(1, L) * (cfg->soft_shadows ? cfg->ss_samples : 1));
+        if (p.cap_nodes > 0x7fffffffull || p.cap_links > 0x7fffffffull || (double)p.cap_shadow > 2.0e9 || widest_segment > 2.0e9) {
+            if (B <= 64) return c->fail(RT_ERR_CAPACITY, "batch too large for 32-bit indices");
+            B /= 2; continue;
+        }
         const size_t need = plan_bytes(p, textures);
         if (need <= budget) return RT_OK;
         B = (long long)((double)B * ((double)budget / (double)need) * 0.97);      // the estimate was short: smaller batches
