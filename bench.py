@@ -337,7 +337,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     st = r.render_device(cfg, block.data_ptr(), want_stats=True)     # ray counts (the counting kernel variants)
     heavy = st.ms_total > 150.0                                      # a frame of hundreds of ms: no extra frames beyond the timed ones
     note(f"first frame {st.ms_total:.1f} ms, {st.total_rays()} rays, {st.batches} batches")
-    shadow_all = None
+    shadow_all = shadow_no_cone = None
     if heavy:
         steps = min(steps, 3); warmup = min(warmup, 1)
     if detail and heavy:
@@ -352,6 +352,9 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
         r.set_option("skip_unlit", 0)                                # how many shadow rays the N.L <= 0 rule leaves untraced
         shadow_all = r.render_device(cfg, block.data_ptr(), want_stats=True).shadow_rays
         r.set_option("skip_unlit", 1)
+        r.set_option("cull_cones", 0)                                # ... and the cone test of soft shadows (tiny scenes)
+        shadow_no_cone = r.render_device(cfg, block.data_ptr(), want_stats=True).shadow_rays
+        r.set_option("cull_cones", 1)
         for _ in range(4):
             r.render_device(cfg, block.data_ptr())
         r.set_option("count_rays", 0)                                # stage times with the kernels the timed frames run
@@ -411,7 +414,9 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
                "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3],
                                   "hits_shaded": tot[5], "as_the_reference_would_trace_them": tot[0] + tot[4],
                                   "shadow_not_traced_because_the_surface_faces_away_from_the_light":
-                                      (shadow_all - st.shadow_rays) if (world == 1 and shadow_all is not None) else None},
+                                      (shadow_all - shadow_no_cone) if (world == 1 and shadow_all is not None) else None,
+                                  "shadow_not_traced_because_no_sample_ray_of_the_pair_can_reach_a_primitive":
+                                      (shadow_no_cone - st.shadow_rays) if (world == 1 and shadow_no_cone is not None) else None},
                "lit_fraction": lit, "stats": st}
     torch.cuda.synchronize(dev)
     torch.cuda.set_stream(torch.cuda.default_stream(dev))      # the contexts' streams die with them
@@ -503,8 +508,10 @@ def main():
                        "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
                        "timing": "ms_per_step = timed wall clock / steps with frames_in_flight independent frames overlapping on the GPU; "
                                  "frame_ms_alone = one frame enqueued and waited for by itself",
-                       "soft_shadow_sampling": "the first reflection of every path is traced gr_samples times (each copy draws its own "
-                                               "shadow samples, as the reference's identical rays do); deeper reflections are traced once",
+                       "soft_shadow_sampling": "the first reflection of every path is recorded gr_samples times (each copy draws its own shadow "
+                                               "samples, as the reference's identical rays do; one traced ray per bundle); deeper reflections once",
+                       "value_counts": "traced rays only: shadow rays whose outcome is certain without tracing (surface facing away from the light; "
+                                       "no sample ray of the pair can reach a primitive) and the identical copies of a reflection ray are not counted",
                        "rays_per_frame": head["rays_per_frame"], "lit_fraction": head["lit_fraction"]},
             "roofline": roofline(st, args.workload, wl["scene"] != "random"),
         }

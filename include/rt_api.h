@@ -199,6 +199,9 @@ void* rt_get_stream(rt_ctx* ctx);
  * "skip_unlit" = 0/1: whether the shadow rays of a (hit, light) pair whose surface faces away from the light are left
  * untraced (default 1; raytracer.cpp:322-336 multiplies their result by max(0, N.L) = 0, so frames are identical;
  * rt_stats.shadow_rays counts traced rays, shadow_rays_ref what the reference traces).
+ * "cull_cones" = 0/1 (soft shadows, scenes of at most 8 primitives): whether the sample rays of a (hit, light) pair are left
+ * untraced when the whole cone from the hit to the light ball provably reaches no primitive (default 1; every sample is then
+ * unblocked whatever the random numbers, so frames are identical; rt_stats.shadow_rays counts traced rays).
  * "count_rays" = 0/1: whether rt_render_device with a statistics pointer counts rays (default 1) or only times the
  * stages, with the kernels plain frames use (the ray counts then read 0).
  * "max_grid" (all kernels) or "grid_primary" / "grid_secondary" / "grid_shadow" / "grid_shade" = workgroups per launch,

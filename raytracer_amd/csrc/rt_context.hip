@@ -216,6 +216,7 @@ struct rt_ctx {
     bool count_rays = true;                  // frames with statistics count rays (off: stage times only, at the speed of plain frames)
     // 0 = chosen per launch (see enqueue_frame)
     int grid_primary = 0, grid_secondary = 0, grid_shadow = 0, grid_shade = 0;
+    bool cull_cones = true;                  // see k_shadow: soft-shadow cones that miss every primitive are not traced
     bool bundle_reflections = true;          // ... as one traced ray with gr_samples hit records (off: gr_samples traced rays)
     bool replicate_reflections = true;       // soft shadows: first reflections traced gr_samples times, each with its own shadow samples
     bool fast_samples = true;                // soft-shadow sample rays: hardware reciprocals instead of IEEE division
@@ -229,7 +230,7 @@ struct rt_ctx {
     DevBuf<int> d_sub_entries_file, d_sub_entries, d_prim_ids;
 
     // device scene
-    DevBuf<float4> d_nodes, d_mats, d_plane_uv, d_texels, d_lights, d_verts, d_edges;
+    DevBuf<float4> d_nodes, d_mats, d_plane_uv, d_plane_bound, d_texels, d_lights, d_verts, d_edges;
     DevBuf<int4> d_leaves, d_tex_desc;
     DevBuf<float4> d_file_planes, d_file_cubes, d_file_spheres, d_leaf_planes, d_leaf_cubes, d_leaf_spheres;
     DevScene scene{};
@@ -327,7 +328,7 @@ void rt_destroy(rt_ctx* c) {
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    DevBuf<float4>* f4s[] = { &c->d_nodes, &c->d_mats, &c->d_plane_uv, &c->d_texels, &c->d_lights, &c->d_verts, &c->d_edges, &c->d_file_planes,
+    DevBuf<float4>* f4s[] = { &c->d_nodes, &c->d_mats, &c->d_plane_uv, &c->d_plane_bound, &c->d_texels, &c->d_lights, &c->d_verts, &c->d_edges, &c->d_file_planes,
                               &c->d_file_cubes, &c->d_file_spheres, &c->d_leaf_planes, &c->d_leaf_cubes, &c->d_leaf_spheres,
                               &c->q_a[0], &c->q_a[1], &c->q_b[0], &c->q_b[1], &c->n_a, &c->n_b, &c->n_c, &c->n_col, &c->accum };
     for (auto* b : f4s) b->release();
@@ -372,6 +373,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "skip_unlit") == 0) { c->skip_unlit = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "count_rays") == 0) { c->count_rays = value != 0; return RT_OK; }
     if (std::strcmp(name, "fast_samples") == 0) { c->fast_samples = value != 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "cull_cones") == 0) { c->cull_cones = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "bundle_reflections") == 0) { c->bundle_reflections = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "replicate_reflections") == 0) { c->replicate_reflections = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "overlap") == 0) { c->overlap = value != 0; c->drop_graphs(); return RT_OK; }
@@ -445,6 +447,7 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
     c->h_edges.assign((size_t)sc->n_plane_verts, f4(0, 0, 0, 0));
     c->h_file_planes.assign((size_t)np * 3, f4(0, 0, 0, 0));
     std::vector<float4> plane_uv((size_t)np * 3, f4(0, 0, 0, 0));
+    std::vector<float4> plane_bound((size_t)np, f4(0, 0, 0, INFINITY));
     rt_parallel_for((size_t)np, 2048, [&](size_t lo, size_t hi, int) {
         for (size_t i = lo; i < hi; ++i) {
             const rt_plane& p = sc->planes[i];
@@ -471,6 +474,18 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
             plane_uv[i * 3 + 0] = f4(us[0], us[1], us[2], ul);
             plane_uv[i * 3 + 1] = f4(vs[0], vs[1], vs[2], vl);
             plane_uv[i * 3 + 2] = f4(s0.x, s0.y, s0.z, 0.0f);
+            {   // sphere around the polygon (k_shadow's cone test): centroid and the farthest vertex, in double
+                double cx = 0, cy = 0, cz = 0;
+                for (int k = 0; k < p.n_verts; ++k) { cx += v[3 * k]; cy += v[3 * k + 1]; cz += v[3 * k + 2]; }
+                cx /= p.n_verts; cy /= p.n_verts; cz /= p.n_verts;
+                double r2 = 0;
+                for (int k = 0; k < p.n_verts; ++k) {
+                    const double dx = v[3 * k] - cx, dy = v[3 * k + 1] - cy, dz = v[3 * k + 2] - cz;
+                    r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+                }
+                const double rr = std::sqrt(r2) * 1.001 + 1e-6;
+                plane_bound[i] = f4((float)cx, (float)cy, (float)cz, (rr == rr && rr < 1e30) ? (float)rr : INFINITY);
+            }
             put_mat((int)i, p.mat);
             // the device tests the polygon in the projection that drops the dominant normal axis (plane.cpp:207-216):
             // store every vertex as (kept, kept, dropped)
@@ -541,6 +556,7 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
     hipStream_t s = c->stream;
     RT_HIP(c, c->d_mats.upload(mats, s));
     RT_HIP(c, c->d_plane_uv.upload(plane_uv, s));
+    RT_HIP(c, c->d_plane_bound.upload(plane_bound, s));
     RT_HIP(c, c->d_verts.upload(c->h_verts_sorted, s));
     RT_HIP(c, c->d_edges.upload(c->h_edges, s));
     RT_HIP(c, c->d_file_planes.upload(c->h_file_planes, s));
@@ -632,7 +648,7 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
         if (!(radius < 1e30f)) { radius = 1e30f; for (int k = 0; k < 3; ++k) if (!(std::fabs(centre[k]) < 1e30f)) centre[k] = 0.0f; }
     }
 
-    d.mats = c->d_mats.p; d.plane_uv = c->d_plane_uv.p; d.tex_desc = c->d_tex_desc.p; d.texels = c->d_texels.p;
+    d.mats = c->d_mats.p; d.plane_uv = c->d_plane_uv.p; d.plane_bound = c->d_plane_bound.p; d.tex_desc = c->d_tex_desc.p; d.texels = c->d_texels.p;
     d.lights = c->d_lights.p; d.n_lights = sc->n_lights;
     d.sub_nodes = c->n_file_nodes ? c->d_sub_nodes_file.p : nullptr;
     d.sub_entries = c->d_sub_entries_file.p; d.file_sub_root = c->file_sub_root;
@@ -1038,6 +1054,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     int fb = cfg->fallback; if (fb == 0) fb = 1;
     f.fallback_full = (fb == 1);
     f.light_radius = cfg->light_radius; f.seed = cfg->seed; f.fast_samples = c->fast_samples ? 1 : 0; f.count_stats = count_stats ? 1 : 0; f.skip_unlit = c->skip_unlit ? 1 : 0;
+    f.cull_cones = c->cull_cones ? 1 : 0;
     f.replicate = (cfg->soft_shadows && c->replicate_reflections) ? 1 : 0;
     // identical reflection rays are traced once and recorded gr_samples times (the packed hit record holds 12-bit copy numbers)
     f.bundle = (f.replicate && !cfg->glossy_reflect && cfg->gr_samples <= 4096 && c->bundle_reflections) ? 1 : 0;

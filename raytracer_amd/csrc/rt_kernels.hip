@@ -926,6 +926,69 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
     }
 }
 
+// Soft shadows of a scene with a handful of primitives: can ANY sample ray of a (hit, light) pair hit anything?  The
+// sample rays start within 0.001 of the hit point p (raytracer.cpp:549) and aim at points of the ball of radius R
+// around the light (raytracer.cpp:541), so their directions lie in the cone around a = (light - p) / D with
+// sin(half angle) = R / D.  A primitive can only be hit if that cone, widened by the angle its bounding sphere
+// (inflated for what the float tests may report outside the geometry, swept over the motion) subtends from p, reaches
+// the direction of its centre; a polygon can also be ruled out when every ray of the cone leaves its plane behind.
+// When nothing can be hit, every sample is unblocked whatever the random numbers are, and none is traced: the counts
+// written are exactly those tracing would give.  Conservative throughout (a "maybe" traces).
+DEVI bool cone_may_hit_sphere(V3 p, V3 a, float sin_t, float cos_t, V3 c, float r) {
+    const V3 v = c - p;
+    const float dv2 = dot(v, v);
+    const float re = r * 1.02f + 2e-3f * (__builtin_amdgcn_sqrtf(dv2) + 1.0f);
+    if (!(dv2 > re * re * 1.0001f)) return true;                        // the apex is inside (or near) the sphere, or NaN
+    const float inv = __builtin_amdgcn_rsqf(dv2);
+    const float sin_b = re * inv, cos_b = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - sin_b * sin_b));
+    const float cos_g = dot(v, a) * inv;                                 // angle between the axis and the centre
+    // reachable iff gamma <= theta + beta; theta + beta >= 90 degrees is never ruled out
+    const float cos_tb = cos_t * cos_b - sin_t * sin_b;
+    return !(cos_tb > 0.0f && cos_g < cos_tb - 1e-3f);
+}
+
+DEVI bool cone_may_hit(const DevScene& sc, bool mb, V3 p, V3 lc, float R) {
+    const V3 ax = lc - p;
+    const float D2 = dot(ax, ax);
+    if (!(D2 > 4.0f * R * R) || !(D2 < 1e30f)) return true;             // inside or near the light ball: no useful cone
+    const float invD = __builtin_amdgcn_rsqf(D2);
+    const V3 a = ax * invD;
+    const float sin_t = R * invD * 1.001f + 1e-4f, cos_t = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - sin_t * sin_t));
+    const DevPrimSet& S = sc.fileset;
+    for (int i = 0; i < S.n_spheres; ++i) {
+        const float4 w0 = S.spheres[2 * i], w1 = S.spheres[2 * i + 1];
+        V3 c = mk(w0.x, w0.y, w0.z); float r = fabsf(w0.w);
+        if (mb) { const V3 e = mk(w1.x, w1.y, w1.z); const V3 h = (e - c) * 0.5f; c = c + h; r += __builtin_amdgcn_sqrtf(dot(h, h)) * 1.001f; }
+        if (cone_may_hit_sphere(p, a, sin_t, cos_t, c, r)) return true;
+    }
+    for (int i = 0; i < S.n_cubes; ++i) {
+        const float4 w0 = S.cubes[6 * i], w1 = S.cubes[6 * i + 1];
+        V3 c = mk(w0.x, w0.y, w0.z); float r = fabsf(w0.w) * 1.7325f;    // half edge x sqrt(3)
+        if (mb) { const V3 e = mk(w1.x, w1.y, w1.z); const V3 h = (e - c) * 0.5f; c = c + h; r += __builtin_amdgcn_sqrtf(dot(h, h)) * 1.001f; }
+        if (cone_may_hit_sphere(p, a, sin_t, cos_t, c, r)) return true;
+    }
+    for (int i = 0; i < S.n_planes; ++i) {
+        const float4 w0 = S.planes[3 * i], w1 = S.planes[3 * i + 1];
+        // Every ray of the cone moves away from the plane, and starts on it or beyond it: plane.cpp:153-156 then computes
+        // t < 0 and rejects.  n.d >= (n.a cos - sqrt(1 - (n.a)^2) sin) |n| over the cone; the start is p + 0.001 d.
+        V3 n = mk(w0.x, w0.y, w0.z);
+        const float nl2 = dot(n, n);
+        bool ruled_out = false;
+        if (nl2 > 1e-20f && nl2 < 1e20f) {
+            const float inl = __builtin_amdgcn_rsqf(nl2);
+            float na = dot(n, a) * inl, h = dot(n, mk(w1.x - p.x, w1.y - p.y, w1.z - p.z)) * inl;   // signed distance of the plane ahead of p
+            if (na < 0.0f) { na = -na; h = -h; }
+            const float least = na * cos_t - __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - na * na)) * sin_t;    // smallest n.d over the cone
+            const float scale = fmaxf(fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fmaxf(fabsf(p.z), 1.0f)), fmaxf(fmaxf(fabsf(w1.x), fabsf(w1.y)), fabsf(w1.z)));
+            ruled_out = least > 0.2f && h < 1e-4f - 2e-6f * scale;      // 0.001 x 0.2 of head start against the rounding of h
+        }
+        if (ruled_out) continue;
+        const float4 bs = sc.plane_bound[i];
+        if (cone_may_hit_sphere(p, a, sin_t, cos_t, mk(bs.x, bs.y, bs.z), bs.w)) return true;
+    }
+    return false;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // shadow: one lane per (hit, light, sample).  Hard shadows (raytracer.cpp:509-530): any hit at any distance
 // blocks.  Soft shadows (raytracer.cpp:534-571): ss_samples rays to points in a ball around the light, blocked
@@ -943,8 +1006,9 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     const int4* s_leaves = SUB ? sc.leaves : (const int4*)(s_mem + 2 * sc.n_nodes);
     int* s_stack = (int*)(s_mem + 2 * sc.n_nodes) + threadIdx.x;                      // [depth][thread], only with SUB
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
-    // The launch's work = chunks of RT_BLOCK shadow rays inside segments; a segment = the hits of one region of one of
-    // the levels lv_begin..lv_end, (hit, light, sample) in that order.  Workgroup b takes chunks b, b + gridDim.x, ...
+    // The launch's work = chunks of RT_BLOCK items inside segments; a segment = the hits of one region of one of the
+    // levels lv_begin..lv_end; an item = a (hit, light) pair or, for sample counts that do not tile a wavefront, a
+    // (hit, light, sample) ray.  Workgroup b takes chunks b, b + gridDim.x, ...
     constexpr int MAX_SEG = RT_MAX_LEVELS * RT_REGIONS;
     __shared__ int s_pre[MAX_SEG + 1];                                  // first chunk of every segment
     __shared__ unsigned s_items[MAX_SEG];                               // shadow rays of the segment
@@ -952,7 +1016,10 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     const int L = sc.n_lights;
     constexpr bool FAST = MODE == 2;
     const int SS = MODE ? f.ss_samples : 1;
-    const unsigned per = (unsigned)(L * SS);                            // the host keeps hits x lights x samples below 2^31
+    // grouped: the SS sample rays of a (hit, light) pair sit side by side inside one wavefront and are counted with a
+    // ballot.  The launch's items are then the PAIRS (see the two phases below), otherwise the rays.
+    const bool grouped = (SS <= 64) && ((SS & (SS - 1)) == 0);
+    const unsigned per = grouped ? (unsigned)L : (unsigned)(L * SS);    // the host keeps a segment's rays below 2^31
     const int n_seg = (lv_end - lv_begin + 1) * w.regions;
     for (int sg = threadIdx.x; sg < n_seg; sg += blockDim.x) {
         const int lv = lv_begin + sg / w.regions, rg = sg % w.regions;
@@ -971,74 +1038,129 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     if (f.use_bvh) stage_bvh(sc, s_nodes, (int4*)(s_mem + 2 * sc.n_nodes), !SUB);
     if (LDSP) stage_prims(sc, s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves);
 
-    const bool grouped = (SS <= 64) && ((SS & (SS - 1)) == 0);           // a (hit, light) group sits inside one wavefront
     const int ss_shift = 31 - __clz(SS);
+    // the cone test loops over every primitive: for scenes with a handful of them
+    const bool cull = f.cull_cones && sc.fileset.n_planes + sc.fileset.n_cubes + sc.fileset.n_spheres <= 8;
     int* __restrict__ out = (int*)w.shadow;
     unsigned long long n_rays = 0;
     const float4 light0 = sc.lights[0];                                 // count > 0 implies a light; the usual scene has one
 
+    // One sample ray: hard shadows (raytracer.cpp:509-530) or sample j of a soft shadow (raytracer.cpp:534-571).
+    auto sample_unblocked = [&](int node, int l, int j, const float4 a, const float4 lt) -> bool {
+        const V3 p = mk(a.x, a.y, a.z);
+        Ray sr; sr.time = a.w;
+        Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
+        if (MODE == 0) {
+            const float4 b = w.n_b[node];
+            sr.d = normalise(mk(lt.x - p.x, lt.y - p.y, lt.z - p.z));
+            sr.o = p + mk(b.x, b.y, b.z) * 1e-2f;                        // raytracer.cpp:515: unflipped geometric normal
+            return !trace<true, SUB>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
+        }
+        const uint32_t path = (uint32_t)f2i(w.n_c[node].z);
+        const uint3 q = pcg3d(path ^ (f.seed * 0x9E3779B1u), (uint32_t)j, (uint32_t)l * 16u + STREAM_SHADOW);
+        const V3 jit = unit_sphere(u01(q.x), u01(q.y), u01(q.z)) * f.light_radius;
+        const V3 h2l = mk(lt.x + jit.x, lt.y + jit.y, lt.z + jit.z) - p;
+        V3 ld; float lightDist;                                          // raytracer.cpp:547,553: unit direction and distance
+        const float l2 = dot(h2l, h2l);
+        if (FAST && l2 > 1e-30f && l2 < 1e30f) { const float rs = __builtin_amdgcn_rsqf(l2); ld = h2l * rs; lightDist = l2 * rs; }
+        else { ld = normalise(h2l); lightDist = len_ref(h2l); }
+        sr.o = p + ld * 0.001f;                                          // raytracer.cpp:549
+        sr.d = ld;
+        // only "closest reported distance < lightDist" is asked for (raytracer.cpp:564)
+        const bool hit = trace<false, SUB, FAST>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best, lightDist);
+        return !(hit && best.t < lightDist);
+    };
+    // raytracer.cpp:322-336: the shadow factor only ever multiplies max(0, N.L).  Where the surface clearly faces away from
+    // the light that product is zero whatever the rays would find, so they are not traced (the count written is 0).
+    // "Clearly": beyond any rounding of the shader's normalised N.L; NaNs fail the test and trace.
+    auto faces_light = [&](const float4 a, const float4 b, const float4 lt) -> bool {
+        if (!f.skip_unlit) return true;
+        const V3 nn = mk(b.x, b.y, b.z), Lr = mk(lt.x - a.x, lt.y - a.y, lt.z - a.z);
+        const float d = dot(nn, Lr);
+        return !(d < 0.0f && d * d > 1e-6f * dot(nn, nn) * dot(Lr, Lr));
+    };
+
     int seg = 0;
+    if (grouped) {
+        // Two phases per round.  (1) One lane per (hit, light) PAIR of a chunk of RT_BLOCK pairs decides what the pair
+        // needs: nothing when the surface faces away from the light (count 0) or when no sample ray can reach any
+        // primitive (count SS, see cone_may_hit), otherwise its SS sample rays, and then queues the pair in LDS.  (2) Queued
+        // pairs are expanded to rays, RT_BLOCK at a time, SS neighbouring lanes per pair, and counted with a ballot.
+        // The per-pair work is so done once, not once per sample, and every wavefront that traces is full of rays that
+        // need tracing (the workgroup's last one aside).
+        __shared__ int s_q[2 * RT_BLOCK];
+        __shared__ int s_qn;
+        if (threadIdx.x == 0) s_qn = 0;
+        __syncthreads();
+        const int pairs_per_pass = RT_BLOCK >> ss_shift;
+        for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
+            while (seg < n_seg - 1 && g >= __builtin_amdgcn_readfirstlane(s_pre[seg + 1])) ++seg;
+            const unsigned i = (unsigned)(g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * RT_BLOCK + threadIdx.x;   // pair of the segment
+            bool queue = false; int item = 0;
+            if (i < (unsigned)__builtin_amdgcn_readfirstlane((int)s_items[seg])) {
+                int dense, l;
+                if (L == 1) { dense = (int)i; l = 0; } else { dense = (int)(i / (unsigned)L); l = (int)(i % (unsigned)L); }
+                const int node = __builtin_amdgcn_readfirstlane(s_nbase[seg]) + dense;
+                item = node * L + l;
+                const float4 a = w.n_a[node], b = w.n_b[node];
+                const float4 lt = (L == 1) ? light0 : sc.lights[l];
+                if (!faces_light(a, b, lt)) out[item] = 0;
+                else if (!SUB && MODE != 0 && cull &&
+                         !cone_may_hit(sc, f.motion_blur != 0, mk(a.x, a.y, a.z), mk(lt.x, lt.y, lt.z), f.light_radius)) out[item] = SS;
+                else queue = true;
+            }
+            {
+                const unsigned long long m = __ballot(queue);
+                int base = 0;
+                if (__lane_id() == 0 && m) base = atomicAdd(&s_qn, __popcll(m));
+                base = __shfl(base, 0, 64);
+                if (queue) s_q[base + __popcll(m & ((1ull << __lane_id()) - 1ull))] = item;
+            }
+            __syncthreads();
+            int qn = s_qn;
+            __syncthreads();                                             // everyone has read the count before anyone appends again
+            const bool last = g + (int)gridDim.x >= n_chunks;
+            while (qn >= pairs_per_pass || (last && qn > 0)) {           // after the last chunk the queue is emptied
+                const int take = min(qn, pairs_per_pass), first = qn - take;
+                const int k = (int)(threadIdx.x >> ss_shift), j = (int)(threadIdx.x & (unsigned)(SS - 1));
+                const bool active = k < take;
+                bool unblocked = false; int it = 0;
+                if (active) {
+                    it = s_q[first + k];
+                    int node, l;
+                    if (L == 1) { node = it; l = 0; } else { node = it / L; l = it % L; }
+                    ++n_rays;
+                    unblocked = sample_unblocked(node, l, j, w.n_a[node], (L == 1) ? light0 : sc.lights[l]);
+                }
+                const unsigned long long m = __ballot(active && unblocked);
+                if (active && j == 0) {
+                    const int lane0 = __lane_id();
+                    const unsigned long long grp = (SS == 64) ? m : ((m >> lane0) & ((1ull << SS) - 1ull));
+                    out[it] = __popcll(grp);
+                }
+                qn = first;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_qn = qn;
+            __syncthreads();
+        }
+        if (f.count_stats) block_stat_add(&w.stats[RT_S_SHADOW], n_rays, s_tmp);
+        return;
+    }
+    // sample counts that do not tile a wavefront: one lane per ray, unblocked samples added with atomics
     for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
         while (seg < n_seg - 1 && g >= __builtin_amdgcn_readfirstlane(s_pre[seg + 1])) ++seg;
         const unsigned i = (unsigned)(g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * RT_BLOCK + threadIdx.x;   // ray of the segment
-        const bool active = i < (unsigned)__builtin_amdgcn_readfirstlane((int)s_items[seg]);
-        bool unblocked = false;
-        int node = 0, l = 0, j = 0;
-        if (active) {
-            unsigned grp;
-            if (grouped) { grp = i >> ss_shift; j = (int)(i & (unsigned)(SS - 1)); } else { grp = i / (unsigned)SS; j = (int)(i % (unsigned)SS); }
-            int dense;
-            if (L == 1) { dense = (int)grp; l = 0; } else { dense = (int)(grp / (unsigned)L); l = (int)(grp % (unsigned)L); }
-            node = __builtin_amdgcn_readfirstlane(s_nbase[seg]) + dense;
-            float4 a = w.n_a[node], b = w.n_b[node];
-            float4 lt = (L == 1) ? light0 : sc.lights[l];
-            V3 p = mk(a.x, a.y, a.z);
-            Ray sr; sr.time = a.w;
-            Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
-            // raytracer.cpp:322-336: the shadow factor only ever multiplies max(0, N.L).  Where the surface clearly faces
-            // away from the light that product is zero whatever the rays would find, so they are not traced (the count
-            // written is 0).  "Clearly": beyond any rounding of the shader's normalised N.L; NaNs fail the test and trace.
-            bool lit_side = true;
-            if (f.skip_unlit) {
-                const V3 nn = mk(b.x, b.y, b.z), Lr = mk(lt.x - p.x, lt.y - p.y, lt.z - p.z);
-                const float d = dot(nn, Lr);
-                lit_side = !(d < 0.0f && d * d > 1e-6f * dot(nn, nn) * dot(Lr, Lr));
-            }
-            if (lit_side) ++n_rays;
-            if (!lit_side) {
-                unblocked = false;
-            } else if (MODE == 0) {
-                V3 nrm = mk(b.x, b.y, b.z);
-                sr.d = normalise(mk(lt.x - p.x, lt.y - p.y, lt.z - p.z));
-                sr.o = p + nrm * 1e-2f;                                  // raytracer.cpp:515: unflipped geometric normal
-                unblocked = !trace<true, SUB>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
-            } else {
-                uint32_t path = (uint32_t)f2i(w.n_c[node].z);
-                uint3 q = pcg3d(path ^ (f.seed * 0x9E3779B1u), (uint32_t)j, (uint32_t)l * 16u + STREAM_SHADOW);
-                V3 jit = unit_sphere(u01(q.x), u01(q.y), u01(q.z)) * f.light_radius;
-                V3 lp = mk(lt.x + jit.x, lt.y + jit.y, lt.z + jit.z);
-                V3 h2l = lp - p;
-                V3 ld; float lightDist;                                  // raytracer.cpp:547,553: unit direction and distance
-                const float l2 = dot(h2l, h2l);
-                if (FAST && l2 > 1e-30f && l2 < 1e30f) { float rs = __builtin_amdgcn_rsqf(l2); ld = h2l * rs; lightDist = l2 * rs; }
-                else { ld = normalise(h2l); lightDist = len_ref(h2l); }
-                sr.o = p + ld * 0.001f;                                  // raytracer.cpp:549
-                sr.d = ld;
-                // only "closest reported distance < lightDist" is asked for (raytracer.cpp:564)
-                bool hit = trace<false, SUB, FAST>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best, lightDist);
-                unblocked = !(hit && best.t < lightDist);
-            }
-        }
-        if (grouped) {
-            unsigned long long m = __ballot(active && unblocked);
-            if (active && j == 0) {
-                int lane0 = __lane_id();
-                unsigned long long g = (SS == 64) ? m : ((m >> lane0) & ((1ull << SS) - 1ull));
-                out[node * L + l] = __popcll(g);
-            }
-        } else if (active && unblocked) {
-            atomicAdd(&out[node * L + l], 1);                            // buffer zeroed by the host for this layout
-        }
+        if (i >= (unsigned)__builtin_amdgcn_readfirstlane((int)s_items[seg])) continue;
+        const unsigned grp = i / (unsigned)SS; const int j = (int)(i % (unsigned)SS);
+        int dense, l;
+        if (L == 1) { dense = (int)grp; l = 0; } else { dense = (int)(grp / (unsigned)L); l = (int)(grp % (unsigned)L); }
+        const int node = __builtin_amdgcn_readfirstlane(s_nbase[seg]) + dense;
+        const float4 a = w.n_a[node], b = w.n_b[node];
+        const float4 lt = (L == 1) ? light0 : sc.lights[l];
+        if (!faces_light(a, b, lt)) continue;                            // the host zeroed the counts for this layout
+        ++n_rays;
+        if (sample_unblocked(node, l, j, a, lt)) atomicAdd(&out[node * L + l], 1);
     }
     if (f.count_stats) block_stat_add(&w.stats[RT_S_SHADOW], n_rays, s_tmp);
 }

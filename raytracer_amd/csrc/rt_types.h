@@ -57,6 +57,7 @@ struct DevScene {
     DevPrimSet fileset;
     const float4* mats;
     const float4* plane_uv;
+    const float4* plane_bound;     // per plane in file order: sphere around its vertices (centre, radius)
     const int4* tex_desc;
     const float4* texels;
     const float4* lights; int n_lights;
@@ -84,6 +85,7 @@ struct DevFrame {
     int fast_samples;              // randomly drawn shadow rays use reciprocal arithmetic (distribution-level parity)
     int skip_unlit;                // shadow rays of (hit, light) pairs whose N.L is clearly negative are not traced
     int replicate;                 // soft shadows: the first reflection of a path is traced gr_samples times (see k_extend)
+    int cull_cones;                // soft shadows of tiny scenes: (hit, light) pairs whose whole cone of sample rays misses everything are not traced
     int bundle;                    // ... as ONE traced ray whose hit is recorded gr_samples times (replicate, no glossy perturbation)
     int count_stats;               // kernels add their ray counts to DevWork::stats (one atomic per workgroup and counter)
     // sharding

@@ -132,3 +132,27 @@ def test_all_effects_on_a_crowded_scene_match_the_restatements_high_sample_rende
     p = psnr(img, gold)
     assert p >= 40.0, f"PSNR {p:.1f} dB"
     assert st.reflection_rays > 0 and st.refraction_rays > 0 and st.shadow_rays > 0
+
+
+@pytest.mark.parametrize("scene,flags", [("ref", ["-ss", "-sss", "16"]), ("ref", ["-r", "-rd", "3", "-ss", "-sss", "16"]), ("ref", ["-u", "-ss", "-sss", "5", "-r"]),
+                                         ("glass_tex", ["-t", "-rd", "2", "-ss", "-sss", "8"]), ("glass", ["-m", "-mbs", "3", "-ss", "-sss", "4", "-r", "-grs", "2"]),
+                                         ("bvh5", ["-ss", "-sss", "16", "-r"]), ("cube_mb", ["-m", "-mbs", "2", "-ss", "-sss", "16"]), ("mirror", ["-r", "-ss", "-sss", "4"]),
+                                         ("blinn", ["-ss", "-sss", "64", "-rd", "2"])])
+def test_untraced_soft_shadow_cones_change_no_pixel(scene, flags, textures_dir):
+    """Soft shadows of small scenes: when the cone of sample rays from a hit to the light ball cannot reach any primitive,
+    the samples are all unblocked whatever the random numbers, and are not traced (option cull_cones, default on).
+    Frames must be bit-identical with the option off, in both arithmetic modes of the sample rays, with fewer rays traced."""
+    cfg, _ = api.parse_args(flags); cfg.seed = 13
+    ls = api.LoadedScene(cases.SCENES[scene](), cfg, textures_dir)
+    for fast in (1, 0):
+        got = []
+        for cull in (1, 0):
+            r = api.Renderer(0); r.set_option("cull_cones", cull); r.set_option("fast_samples", fast)
+            r.upload(ls, with_bvh=bool(cfg.bvh))
+            img, st = r.render(cfg)
+            got.append((img, st)); r.close()
+        assert got[0][0].max() > 0 and np.array_equal(got[0][0], got[1][0]), f"{(got[0][0] != got[1][0]).any(axis=2).sum()} pixels differ (fast_samples {fast})"
+        on, off = got[0][1], got[1][1]
+        assert (on.shadow_rays_ref, on.reflection_rays, on.nodes_shaded) == (off.shadow_rays_ref, off.reflection_rays, off.nodes_shaded)
+        assert on.shadow_rays <= off.shadow_rays
+    ls.close()
