@@ -348,6 +348,15 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
                       "launches_extend_primary", "launches_extend_secondary", "launches_shadow", "launches_shade"):
             setattr(st, field, getattr(tm, field))
         note(f"stage times: {tm.ms_total:.1f} ms")
+    elif detail and args.no_variants:
+        for _ in range(4):
+            r.render_device(cfg, block.data_ptr())
+        r.set_option("count_rays", 0)
+        tm = r.render_device(cfg, block.data_ptr(), want_stats=True)
+        r.set_option("count_rays", 1)
+        for field in ("ms_extend_primary", "ms_extend_secondary", "ms_shadow", "ms_shade", "ms_other", "ms_total",
+                      "launches_extend_primary", "launches_extend_secondary", "launches_shadow", "launches_shade"):
+            setattr(st, field, getattr(tm, field))
     elif detail:
         r.set_option("skip_unlit", 0)                                # how many shadow rays the N.L <= 0 rule leaves untraced
         shadow_all = r.render_device(cfg, block.data_ptr(), want_stats=True).shadow_rays
@@ -442,6 +451,8 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a one-GPU machine: every rank uses GPU 0 (use with --backend gloo)")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="profiling runs: no frames with other library options (the counts of untraced shadow rays are then not reported)")
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks, initialise the process group, reduce one number, print it and stop (needs no GPU)")
     args = ap.parse_args()

@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 # forked shadow stream two kernels share the GPU and each one's own duration stretches).
 export RT_BENCH_OPTS=${RT_BENCH_OPTS:-overlap=0,graphs=0}
 # one frame at a time: frames in flight share the GPU and stretch every kernel's own duration
-ARGS="--workload $WL --steps 5 --warmup 1 --no-cpu-baseline --no-scaling-4k --frames-in-flight 1 $*"
+ARGS="--workload $WL --steps 5 --warmup 1 --no-cpu-baseline --no-scaling-4k --no-variants --frames-in-flight 1 $*"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $ARGS > "$OUT/pmc_fetch.log" 2>&1 || { echo "fetch pass failed"; tail -5 "$OUT/pmc_fetch.log"; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $ARGS > "$OUT/pmc_write.log" 2>&1 || { echo "write pass failed"; tail -5 "$OUT/pmc_write.log"; exit 1; }
