@@ -255,7 +255,8 @@ uint64_t rt_noalloc_capacity(void);
  * as rt_render_device wrote it); rgb_out_dev = res_y*res_x*3 bytes row-major.  Enqueue only. */
 int rt_assemble_tiles(rt_ctx* ctx, const void* tiles_dev, int32_t world, void* rgb_out_dev);
 
-/* Blocks until everything enqueued on the context's stream has finished. */
+/* Blocks until everything enqueued on the context's stream has finished.  RT_ERR_CAPACITY if the most recent frame found a
+ * work buffer full (its image is then incomplete; the capacities are worst cases, so this indicates a defect). */
 int rt_synchronize(rt_ctx* ctx);
 
 const char* rt_last_error(const rt_ctx* ctx);   /* ctx may be NULL: error of the last failed rt_create */

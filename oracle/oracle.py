@@ -53,7 +53,8 @@ def parse_args(flags: list[str]) -> OrcConfig:
     argv = [b"raytracer"] + [f.encode() for f in flags]
     arr = (C.c_char_p * len(argv))(*argv)
     cfg = OrcConfig()
-    lib().orc_parse_args(len(argv), arr, C.byref(cfg), None, 0)
+    if lib().orc_parse_args(len(argv), arr, C.byref(cfg), None, 0) != 0:
+        raise ValueError(f"the reference aborts on these flags (std::stoi throws): {flags}")
     return cfg
 
 

@@ -47,33 +47,47 @@ void orc_default_config(orc_config* c) {
     c->dof = 0; c->dofSamples = 16; c->motionBlur = 0; c->mbSamples = 16;
 }
 
+/* std::stoi as config.cpp:19,27,35,47,63,71 uses it: optional white space and sign, then digits; anything after the digits
+ * is ignored; no digit at all (or a value outside int) throws, and the reference, which catches nothing, aborts.
+ * Returns 0 and stores the value, or -1 for what would throw. */
+static int stoi_like(const char* s, int* out) {
+    char* end = NULL;
+    errno = 0;
+    long v = strtol(s, &end, 10);
+    if (end == s || errno == ERANGE || v > 2147483647L || v < -2147483647L - 1) return -1;
+    *out = (int)v;
+    return 0;
+}
+
+/* Returns 0, or -1 where the reference would abort on an uncaught std::invalid_argument / std::out_of_range. */
 int orc_parse_args(int argc, const char* const* argv, orc_config* c, char* out_name, int out_name_cap) {
+    int bad = 0;
     orc_default_config(c);
     if (out_name && out_name_cap > 0) snprintf(out_name, (size_t)out_name_cap, "output.ppm");
 #define IS(a, b) (strcmp(arg, a) == 0 || strcmp(arg, b) == 0)
     for (int i = 1; i < argc; ++i) {
         const char* arg = argv[i];
         if (IS("-ss", "--soft_shadows")) c->softShadows = 1;
-        else if (IS("-sss", "--ss_samples") && i + 1 < argc) c->SSsamples = atoi(argv[++i]);
+        else if (IS("-sss", "--ss_samples") && i + 1 < argc) bad |= stoi_like(argv[++i], &c->SSsamples);
         else if (IS("-gr", "--glossy_reflect")) c->glossyReflect = 1;
-        else if (IS("-grs", "--gr_samples") && i + 1 < argc) c->GRsamples = atoi(argv[++i]);
+        else if (IS("-grs", "--gr_samples") && i + 1 < argc) bad |= stoi_like(argv[++i], &c->GRsamples);
         else if (IS("-aa", "--antialiasing")) c->antiAliasing = 1;
-        else if (IS("-aas", "--aa_samples") && i + 1 < argc) c->AAsamples = atoi(argv[++i]);
+        else if (IS("-aas", "--aa_samples") && i + 1 < argc) bad |= stoi_like(argv[++i], &c->AAsamples);
         else if (IS("-u", "--unaccelerated")) c->bvh = 0;
         else if (IS("-r", "--reflections")) c->reflectRefractDepth = 1;
-        else if (IS("-rd", "--reflect_depth") && i + 1 < argc) c->reflectRefractDepth = atoi(argv[++i]);
+        else if (IS("-rd", "--reflect_depth") && i + 1 < argc) bad |= stoi_like(argv[++i], &c->reflectRefractDepth);
         else if (IS("-t", "--texture_mapping")) c->textures = 1;
         else if (IS("-dof", "--depthoffield")) c->dof = 1;
-        else if (IS("-dofs", "--dof_samples") && i + 1 < argc) c->dofSamples = atoi(argv[++i]);
+        else if (IS("-dofs", "--dof_samples") && i + 1 < argc) bad |= stoi_like(argv[++i], &c->dofSamples);
         else if (IS("-m", "--motion-blur")) c->motionBlur = 1;
-        else if (IS("-mbs", "--mb_samples") && i + 1 < argc) c->mbSamples = atoi(argv[++i]);
+        else if (IS("-mbs", "--mb_samples") && i + 1 < argc) bad |= stoi_like(argv[++i], &c->mbSamples);
         else if (IS("-o", "--output") && i + 1 < argc) {
             ++i;
             if (out_name && out_name_cap > 0) snprintf(out_name, (size_t)out_name_cap, "%s", argv[i]);
         } else fprintf(stderr, "Unknown flag: %s\n", arg);
     }
 #undef IS
-    return 0;
+    return bad ? -1 : 0;
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -249,6 +249,7 @@ struct rt_ctx {
     DevBuf<unsigned long long> stats;
     DevBuf<unsigned char> out_tmp;
     unsigned long long last_batches = 0;
+    const unsigned long long* last_flag = nullptr;   // overflow flag of the most recent frame (device memory)
     std::vector<hipEvent_t> event_pool;
     // Captured launch sequences of whole frames (rt_render_device without statistics), replayed with one
     // hipGraphLaunch.  A frame is captured the second time it is asked for with the same configuration, output
@@ -385,7 +386,12 @@ const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : g_creat
 int rt_synchronize(rt_ctx* c) {
     if (!c) return RT_ERR_ARG;
     RT_HIP(c, hipSetDevice(c->device));
+    // Frames enqueued without statistics are never looked at by the host; their overflow flag (set by a kernel that
+    // found a work buffer full - the capacities are worst cases, so this should be unreachable) is read here.
+    unsigned long long flag = 0;
+    if (c->last_flag) RT_HIP(c, hipMemcpyAsync(&flag, c->last_flag, sizeof flag, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (flag) return c->fail(RT_ERR_CAPACITY, "a work buffer overflowed during a frame; its image is incomplete");
     return RT_OK;
 }
 
@@ -1136,6 +1142,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         w.shadow = c->shadow.p; w.link = c->link.p; w.accum = c->accum.p; w.ctr = c->ctr.p; w.stats = c->stats.p;
     }
     w.cap_nodes = (unsigned)cap_nodes;
+    c->last_flag = w.stats + RT_S_ERR;
     for (int d = 0; d <= D + 2 && d < RT_MAX_LEVELS; ++d) {
         w.node_off[d] = (int)node_off[(size_t)std::min(d, D + 1)]; w.link_off[d] = (int)link_off[(size_t)d];
         w.node_rcap[d] = d <= D ? (int)rcap[(size_t)d] : 0; w.link_rcap[d] = (d >= 1 && d <= D) ? (int)rcap[(size_t)d] : 0;
@@ -1297,7 +1304,7 @@ int rt_render_device(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev, rt_stat
 int rt_render_device_noalloc(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev) {
     if (!c || !cfg || !rgb_out_dev) return RT_ERR_ARG;
     // plain launches (instantiating a frame graph allocates), no statistics (the event pool may have to grow)
-    return enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, false, nullptr, false, true);
+    return enqueue_frame(c, cfg, (unsigned char*)rgb_out_dev, true, nullptr, false, true);
 }
 
 uint64_t rt_noalloc_capacity(void) { return RT_NOALLOC_BYTES; }
