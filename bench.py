@@ -183,6 +183,11 @@ def roofline(st, workload: str, small_scene: bool) -> dict:
                 k["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
                 k["valu_TFLOPs_equiv"] = c["SQ_INSTS_VALU"] * FLOP_PER_VALU_INST / secs / 1e12
                 k["valu_issue_frac"] = k["valu_TFLOPs_equiv"] / VALU_PEAK_TFLOPS
+            if c.get("SQ_ACTIVE_INST_VALU"):
+                # time the vector ALUs spend executing (the counter ticks once per four cycles of an instruction in flight),
+                # as a share of the launch: double-precision and transcendental instructions hold a SIMD longer than the two
+                # cycles the issue-slot figure above prices every instruction at
+                k["valu_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * secs * 2.4e9)
             if c.get("hbm_bytes_per_launch") is not None:
                 k["hbm_bytes_per_launch"] = c["hbm_bytes_per_launch"]
                 k["hbm_GBps"] = c["hbm_bytes_per_launch"] / 1e9 / secs
@@ -202,11 +207,13 @@ def roofline(st, workload: str, small_scene: bool) -> dict:
            "hbm_algorithmic": alg, "l2_hit_rate": d.get("l2_hit_rate"), "by_kernel": kernels}
     if small_scene and "valu_issue_frac" in d:
         out.update(bound="valu", achieved=d["valu_TFLOPs_equiv"], peak=VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=d["valu_issue_frac"],
+                   valu_busy_frac=d.get("valu_busy_frac"),
                    note="a handful of primitives: nodes, primitive records and materials are served from LDS, HBM carries only the hit tree "
                         "and the ray queues, and the kernels are bound by vector-instruction issue (IEEE divides, double-precision "
                         "normalisation kept for bit parity).  achieved = vector instructions of the launch (rocprofv3 SQ_INSTS_VALU, "
                         "committed counter pass) x 128 flop (64 lanes x one FMA) / launch duration measured live: the FP32 vector rate "
-                        "the used issue slots stand for; frac = share of the chip's vector issue slots in use")
+                        "the used issue slots stand for; frac = share of the chip's vector issue slots in use; valu_busy_frac = share of the "
+                        "launch during which the vector ALUs execute (SQ_ACTIVE_INST_VALU), which prices slow instructions at what they cost")
     elif not small_scene and d.get("hbm_GBps"):
         out.update(bound="hbm", achieved=d["hbm_GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=d["hbm_GBps"] / HBM_PEAK_GBS,
                    note="achieved = HBM bytes of the launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, committed counter pass) / launch duration "
@@ -358,10 +365,9 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
                       "launches_extend_primary", "launches_extend_secondary", "launches_shadow", "launches_shade"):
             setattr(st, field, getattr(tm, field))
     elif detail:
-        r.set_option("skip_unlit", 0)                                # how many shadow rays the N.L <= 0 rule leaves untraced
+        r.set_option("skip_unlit", 0); r.set_option("cull_cones", 0)  # how many shadow rays the N.L <= 0 rule leaves untraced ...
         shadow_all = r.render_device(cfg, block.data_ptr(), want_stats=True).shadow_rays
-        r.set_option("skip_unlit", 1)
-        r.set_option("cull_cones", 0)                                # ... and the cone test of soft shadows (tiny scenes)
+        r.set_option("skip_unlit", 1)                                # ... and the cone test of soft shadows (tiny scenes)
         shadow_no_cone = r.render_device(cfg, block.data_ptr(), want_stats=True).shadow_rays
         r.set_option("cull_cones", 1)
         for _ in range(4):
