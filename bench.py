@@ -263,14 +263,15 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
             ls = api.LoadedScene(cases.blend_scene(wl["scene"][6:], W, H), cfg, str(cases.TEXTURES))
         else:
             from raytracer_amd import scenegen as sg
-            ls = api.ArrayScene(sg.random_prims(wl["n"], wl.get("seed", 42), moving=bool(cfg.motion_blur)), (W, H), moving=bool(cfg.motion_blur))
+            moving = bool(cfg.motion_blur) and os.environ.get("RT_BENCH_STATIC", "") != "1"
+            ls = api.ArrayScene(sg.random_prims(wl["n"], wl.get("seed", 42), moving=moving), (W, H), moving=moving)
     ls = rdist.broadcast_scene(ls, bool(cfg.bvh), 0, on_dev)
     # Frames in flight: consecutive frames are independent, so P contexts (each with its own work buffers and stream)
     # render them concurrently; a frame's small launches (deep recursion levels) then fill the other frames' gaps.
     # Four by default: one per hardware queue of the process (more share queues and lose again).  Not used for frames
     # of many samples per pixel, which keep the GPU busy on their own.
     spp = cfg.samples_per_pixel()
-    P = max(1, frames_in_flight) if (spp < 16 and W * H <= 1920 * 1080) else 1
+    P = max(1, frames_in_flight) if (spp <= 64 and W * H <= 1920 * 1080) else 1
     if world > 1:
         P = min(P, 3)                                 # the communicator's stream takes the fourth hardware queue
 
