@@ -27,9 +27,10 @@ hipError_t rt_build_scene_bounds(hipStream_t s, const DevPrimSet& set, float out
 // Builds the hierarchies of `groups` (host array, items numbered group after group) over `set`.
 // sphere_e = squared-distance rounding allowance of the sphere test; nodes / entries = device arrays (absolute node
 // indices; a group's entries start at 4 * node_base).  When final6 != NULL it receives the union of the (enlarged) item boxes.
-// Synchronises the stream.
+// motion = node records of 8 words (boxes at time 0 and their change until time 1) instead of 4 (boxes over the whole
+// motion).  Synchronises the stream.
 hipError_t rt_build_hierarchies(hipStream_t s, const DevPrimSet& set, const BuildGroup* groups, int n_groups, long long n_items,
-                                double sphere_e, float4* nodes, int* entries, float final6[6]);
+                                double sphere_e, bool motion, float4* nodes, int* entries, float final6[6]);
 
 // Leaf-order copies of the file-order primitive records.  leaf_desc (host): per leaf (first id in prim_ids, planes,
 // cubes, spheres) and (first leaf-order plane, cube, sphere, 0).  prim_ids_dev holds validated indices.

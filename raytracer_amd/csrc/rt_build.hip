@@ -43,32 +43,38 @@ DEVI void db_add(DBox& b, float x, float y, float z) {
     b.mn[1] = (y < b.mn[1]) ? y : b.mn[1]; b.mx[1] = (b.mx[1] < y) ? y : b.mx[1];
     b.mn[2] = (z < b.mn[2]) ? z : b.mn[2]; b.mx[2] = (b.mx[2] < z) ? z : b.mx[2];
 }
-DEVI void db_grow(DBox& b) {
+// Enlargement per axis that covers the rounding of the reference's own position arithmetic (relative to the box's
+// largest coordinate or width).
+DEVI void db_slack(const DBox& b, float e[3]) {
     for (int i = 0; i < 3; ++i) {
         float m = fabsf(b.mn[i]), M = fabsf(b.mx[i]), w = b.mx[i] - b.mn[i];
         float big = (m < M) ? M : m; big = (big < w) ? w : big;
-        float e = 1e-5f * big + 1e-6f;
-        b.mn[i] -= e; b.mx[i] += e;
+        e[i] = 1e-5f * big + 1e-6f;
     }
 }
+DEVI void db_grow_by(DBox& b, const float e[3]) { for (int i = 0; i < 3; ++i) { b.mn[i] -= e[i]; b.mx[i] += e[i]; } }
 
-// True bounds of item k of a group (planes, then cubes, then spheres); returns the packed entry.
-DEVI unsigned item_box(const DevPrimSet& S, const BuildGroup& g, int k, double sphere_e, DBox& b) {
-    db_clear(b);
-    if (k < g.pn) {
-        const int idx = g.p0 + k;
+// True bounds of one primitive of a set (entry = class << 30 | index): `sw` = everything it occupies for ray times in
+// [0,1]; `t0` / `t1` (optional) = what it occupies at time 0 and at time 1.  A primitive moves on a straight line
+// (lerp of its two locations, sphere.cpp:123, cube.cpp:131), so the box interpolated between t0 and t1 bounds it at
+// any time in between; all three carry the enlargement computed for the swept box.
+DEVI void prim_boxes(const DevPrimSet& S, unsigned entry, double sphere_e, DBox& sw, DBox* t0, DBox* t1) {
+    const int cls = (int)(entry >> 30), idx = (int)(entry & 0x3fffffffu);
+    db_clear(sw);
+    if (t0) { db_clear(*t0); db_clear(*t1); }
+    float e[3];
+    if (cls == 0) {
         const float4 w0 = S.planes[3 * (size_t)idx], w1 = S.planes[3 * (size_t)idx + 1];
         const int first = f2i(w0.w), nv = f2i(w1.w) & 0xffff, drop = f2i(w1.w) >> 16;
         for (int v = 0; v < nv; ++v) {                        // vertices are stored projected: (kept, kept, dropped)
             float4 p = S.verts[first + v];
-            if (drop == 0) db_add(b, p.z, p.x, p.y); else if (drop == 1) db_add(b, p.x, p.z, p.y); else db_add(b, p.x, p.y, p.z);
+            if (drop == 0) db_add(sw, p.z, p.x, p.y); else if (drop == 1) db_add(sw, p.x, p.z, p.y); else db_add(sw, p.x, p.y, p.z);
         }
-        db_grow(b);
-        return (unsigned)idx;
+        db_slack(sw, e); db_grow_by(sw, e);
+        if (t0) { *t0 = sw; *t1 = sw; }
+        return;
     }
-    k -= g.pn;
-    if (k < g.cn) {
-        const int idx = g.c0 + k;
+    if (cls == 1) {
         const float4* q = S.cubes + 6 * (size_t)idx;
         const float4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
         const float cx = w2.x, sx = w2.y, cy = w2.z, sy = w2.w, cz = w3.x, sz = w3.y, scale = w0.w;
@@ -77,26 +83,41 @@ DEVI unsigned item_box(const DevPrimSet& S, const BuildGroup& g, int k, double s
             float y1 = y * cx - z * sx, z1 = y * sx + z * cx;
             float x2 = x * cy + z1 * sy, z2 = -x * sy + z1 * cy;
             float rx = (x2 * cz - y1 * sz) * scale, ry = (x2 * sz + y1 * cz) * scale, rz = z2 * scale;
-            db_add(b, rx + w0.x, ry + w0.y, rz + w0.z);
-            db_add(b, rx + w1.x, ry + w1.y, rz + w1.z);
+            db_add(sw, rx + w0.x, ry + w0.y, rz + w0.z);
+            db_add(sw, rx + w1.x, ry + w1.y, rz + w1.z);
+            if (t0) { db_add(*t0, rx + w0.x, ry + w0.y, rz + w0.z); db_add(*t1, rx + w1.x, ry + w1.y, rz + w1.z); }
         }
-        db_grow(b);
-        return (1u << 30) | (unsigned)idx;
+        db_slack(sw, e); db_grow_by(sw, e);
+        if (t0) { db_grow_by(*t0, e); db_grow_by(*t1, e); }
+        return;
     }
-    k -= g.cn;
-    const int idx = g.s0 + k;
     const float4 w0 = S.spheres[2 * (size_t)idx], w1 = S.spheres[2 * (size_t)idx + 1];
     const float r = fabsf(w0.w);
-    db_add(b, w0.x - r, w0.y - r, w0.z - r); db_add(b, w0.x + r, w0.y + r, w0.z + r);
-    db_add(b, w1.x - r, w1.y - r, w1.z - r); db_add(b, w1.x + r, w1.y + r, w1.z + r);
-    db_grow(b);
+    db_add(sw, w0.x - r, w0.y - r, w0.z - r); db_add(sw, w0.x + r, w0.y + r, w0.z + r);
+    db_add(sw, w1.x - r, w1.y - r, w1.z - r); db_add(sw, w1.x + r, w1.y + r, w1.z + r);
+    if (t0) {
+        db_add(*t0, w0.x - r, w0.y - r, w0.z - r); db_add(*t0, w0.x + r, w0.y + r, w0.z + r);
+        db_add(*t1, w1.x - r, w1.y - r, w1.z - r); db_add(*t1, w1.x + r, w1.y + r, w1.z + r);
+    }
+    db_slack(sw, e);
     if (sphere_e > 0.0) {
         // sphere.cpp:131-139 forms |l|^2 - tca^2 in float: a reported hit lies within sqrt(r^2 + e) of the centre
         const double rd = (double)r;
         const float extra = (float)(sqrt(rd * rd + sphere_e) - rd) * 1.01f;
-        if (extra < INFINITY) for (int i = 0; i < 3; ++i) { b.mn[i] -= extra; b.mx[i] += extra; }
+        if (extra < INFINITY) for (int i = 0; i < 3; ++i) e[i] += extra;
     }
-    return (2u << 30) | (unsigned)idx;
+    db_grow_by(sw, e);
+    if (t0) { db_grow_by(*t0, e); db_grow_by(*t1, e); }
+}
+
+// True bounds of item k of a group (planes, then cubes, then spheres); returns the packed entry.
+DEVI unsigned item_box(const DevPrimSet& S, const BuildGroup& g, int k, double sphere_e, DBox& b) {
+    unsigned entry;
+    if (k < g.pn) entry = (unsigned)(g.p0 + k);
+    else if (k < g.pn + g.cn) entry = (1u << 30) | (unsigned)(g.c0 + k - g.pn);
+    else entry = (2u << 30) | (unsigned)(g.s0 + k - g.pn - g.cn);
+    prim_boxes(S, entry, sphere_e, b, nullptr, nullptr);
+    return entry;
 }
 
 DEVI float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) { float t = __shfl_xor(v, o); v = (t < v) ? t : v; } return v; }
@@ -252,48 +273,95 @@ DEVI void box_union(float4& mn, float4& mx, float4 a, float4 b) {
     mx.x = fmaxf(mx.x, b.x); mx.y = fmaxf(mx.y, b.y); mx.z = fmaxf(mx.z, b.z);
 }
 
+// Node records.  Static scenes: 4 words per node, (minL, refL) (maxL, cntL) (minR, refR) (maxR, cntR) - both children's
+// boxes over the whole motion.  Scenes with moving primitives: 8 words per node, the same four words for time 0 and
+// four words that hold, per child, how far the box's corners move between time 0 and time 1; the traversal adds
+// time x that to the first four (while the hierarchy is being built the second four hold the boxes at time 1
+// themselves, k_motion_deltas converts them at the end).  Two siblings share a block of 16 words - both time-0 records,
+// then both motion records (rt_sub_motion_offset) - so that a step of a ray at time 0 reads one 128-byte line.
+//
 // Lowest interior level: node = parent of two runs of sorted items.
-__global__ __launch_bounds__(256) void k_leaf_parents(const BuildGroup* __restrict__ groups, const float4* __restrict__ boxes,
+template <bool MOTION>
+DEVI float4* node_words(float4* nodes, int node_base, long long h) {
+    return nodes + (MOTION ? 8 * (size_t)node_base + rt_sub_motion_offset((int)h) : 4 * ((size_t)node_base + (size_t)h));
+}
+
+template <bool MOTION>
+__global__ __launch_bounds__(256) void k_leaf_parents(DevPrimSet S, const BuildGroup* __restrict__ groups, double sphere_e, const float4* __restrict__ boxes,
                                                       const unsigned* __restrict__ sorted, float4* __restrict__ nodes) {
+    constexpr int ST = MOTION ? 8 : 4;
     const BuildGroup g = groups[blockIdx.y];
     const long long half = 1ll << (g.depth - 1);
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < half; t += (long long)gridDim.x * blockDim.x) {
-        float4 out[4];
+        float4 out[ST];
         for (int side = 0; side < 2; ++side) {
             const long long j = 2 * t + side;
             const long long a = (j * (long long)g.n) >> g.depth, b = ((j + 1) * (long long)g.n) >> g.depth;
             float4 mn = make_float4(INFINITY, INFINITY, INFINITY, 0.0f), mx = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+            float4 mn1 = mn, mx1 = mx;
             for (long long p = a; p < b; ++p) {
                 const size_t item = sorted[(size_t)g.item_base + (size_t)p];
-                box_union(mn, mx, boxes[2 * item], boxes[2 * item + 1]);
+                if (MOTION) {
+                    DBox sw, t0, t1;
+                    prim_boxes(S, (unsigned)f2i(boxes[2 * item].w), sphere_e, sw, &t0, &t1);
+                    box_union(mn, mx, make_float4(t0.mn[0], t0.mn[1], t0.mn[2], 0.0f), make_float4(t0.mx[0], t0.mx[1], t0.mx[2], 0.0f));
+                    box_union(mn1, mx1, make_float4(t1.mn[0], t1.mn[1], t1.mn[2], 0.0f), make_float4(t1.mx[0], t1.mx[1], t1.mx[2], 0.0f));
+                } else {
+                    box_union(mn, mx, boxes[2 * item], boxes[2 * item + 1]);
+                }
             }
             mn.w = i2f(~(int)(4 * ((long long)g.node_base + j)));
             mx.w = i2f((int)(b - a));
             out[2 * side] = mn; out[2 * side + 1] = mx;
+            if (MOTION) { out[4 + 2 * side] = mn1; out[4 + 2 * side + 1] = mx1; }
         }
-        float4* nd = nodes + 4 * ((size_t)g.node_base + (size_t)(half - 1 + t));
-        nd[0] = out[0]; nd[1] = out[1]; nd[2] = out[2]; nd[3] = out[3];
+        float4* nd = node_words<MOTION>(nodes, g.node_base, half - 1 + t);
+        for (int k = 0; k < 4; ++k) nd[k] = out[k];
+        if (MOTION) for (int k = 0; k < 4; ++k) nd[8 + k] = out[4 + k];
     }
 }
 
 // Level `depth - height` of every group that is at least `height` levels deep (height >= 2): union of the children.
+template <bool MOTION>
 __global__ __launch_bounds__(256) void k_upper_level(const BuildGroup* __restrict__ groups, int height, float4* __restrict__ nodes) {
+    constexpr int ST = MOTION ? 8 : 4;
     const BuildGroup g = groups[blockIdx.y];
     if (g.depth < height) return;
     const long long width = 1ll << (g.depth - height);
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < width; t += (long long)gridDim.x * blockDim.x) {
         const long long i = width - 1 + t;
-        float4 out[4];
+        float4 out[ST];
         for (int side = 0; side < 2; ++side) {
             const long long ch = 2 * i + 1 + side;
-            const float4* cd = nodes + 4 * ((size_t)g.node_base + (size_t)ch);
+            const float4* cd = node_words<MOTION>(nodes, g.node_base, ch);
             float4 mn = cd[0], mx = cd[1];
             box_union(mn, mx, cd[2], cd[3]);
             mn.w = i2f(g.node_base + (int)ch); mx.w = i2f(0);
             out[2 * side] = mn; out[2 * side + 1] = mx;
+            if (MOTION) {
+                float4 mn1 = cd[8], mx1 = cd[9];
+                box_union(mn1, mx1, cd[10], cd[11]);
+                mn1.w = 0.0f; mx1.w = 0.0f;
+                out[4 + 2 * side] = mn1; out[4 + 2 * side + 1] = mx1;
+            }
         }
-        float4* nd = nodes + 4 * ((size_t)g.node_base + (size_t)i);
-        nd[0] = out[0]; nd[1] = out[1]; nd[2] = out[2]; nd[3] = out[3];
+        float4* nd = node_words<MOTION>(nodes, g.node_base, i);
+        for (int k = 0; k < 4; ++k) nd[k] = out[k];
+        if (MOTION) for (int k = 0; k < 4; ++k) nd[8 + k] = out[4 + k];
+    }
+}
+
+// Motion words of every 8-word node: box at time 1 -> (box at time 1) - (box at time 0).  Corners that are not finite
+// at either time get a NaN difference, which makes the traversal visit the child.
+__global__ __launch_bounds__(256) void k_motion_deltas(const BuildGroup* __restrict__ groups, float4* __restrict__ nodes) {
+    const BuildGroup g = groups[blockIdx.y];
+    const long long n = (1ll << g.depth) - 1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float4* nd = node_words<true>(nodes, g.node_base, i);
+        for (int k = 0; k < 4; ++k) {
+            const float4 a = nd[k], b = nd[8 + k];
+            nd[8 + k] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, 0.0f);
+        }
     }
 }
 
@@ -358,7 +426,7 @@ hipError_t rt_build_scene_bounds(hipStream_t s, const DevPrimSet& set, float out
 }
 
 hipError_t rt_build_hierarchies(hipStream_t s, const DevPrimSet& set, const BuildGroup* groups, int n_groups, long long n_items,
-                                double sphere_e, float4* nodes, int* entries, float final6[6]) {
+                                double sphere_e, bool motion, float4* nodes, int* entries, float final6[6]) {
     if (final6) for (int i = 0; i < 3; ++i) { final6[i] = INFINITY; final6[3 + i] = -INFINITY; }
     if (n_groups <= 0 || n_items <= 0) return hipSuccess;
     if (n_groups > 65535 || n_items > 0x7fffffffll) return hipErrorInvalidValue;
@@ -406,9 +474,16 @@ hipError_t rt_build_hierarchies(hipStream_t s, const DevPrimSet& set, const Buil
     }
 
     hipLaunchKernelGGL(k_entries, dim3(grid_for(1ll << max_depth), n_groups), dim3(256), 0, s, d_groups, d_boxes, d_ord, entries);
-    hipLaunchKernelGGL(k_leaf_parents, dim3(grid_for(((long long)max_n + 3) / 4), n_groups), dim3(256), 0, s, d_groups, d_boxes, d_ord, nodes);
-    for (int h = 2; h <= max_depth; ++h)
-        hipLaunchKernelGGL(k_upper_level, dim3(grid_for(1ll << (max_depth - h)), n_groups), dim3(256), 0, s, d_groups, h, nodes);
+    if (motion) {
+        hipLaunchKernelGGL(k_leaf_parents<true>, dim3(grid_for(((long long)max_n + 3) / 4), n_groups), dim3(256), 0, s, set, d_groups, sphere_e, d_boxes, d_ord, nodes);
+        for (int h = 2; h <= max_depth; ++h)
+            hipLaunchKernelGGL(k_upper_level<true>, dim3(grid_for(1ll << (max_depth - h)), n_groups), dim3(256), 0, s, d_groups, h, nodes);
+        hipLaunchKernelGGL(k_motion_deltas, dim3(grid_for(1ll << max_depth), n_groups), dim3(256), 0, s, d_groups, nodes);
+    } else {
+        hipLaunchKernelGGL(k_leaf_parents<false>, dim3(grid_for(((long long)max_n + 3) / 4), n_groups), dim3(256), 0, s, set, d_groups, sphere_e, d_boxes, d_ord, nodes);
+        for (int h = 2; h <= max_depth; ++h)
+            hipLaunchKernelGGL(k_upper_level<false>, dim3(grid_for(1ll << (max_depth - h)), n_groups), dim3(256), 0, s, d_groups, h, nodes);
+    }
     BUILD_TRY(hipGetLastError());
     unsigned red[6];
     if (final6) BUILD_TRY(hipMemcpyAsync(red, d_red, sizeof red, hipMemcpyDeviceToHost, s));

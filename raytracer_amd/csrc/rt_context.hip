@@ -222,6 +222,8 @@ struct rt_ctx {
     bool fast_samples = true;                // soft-shadow sample rays: hardware reciprocals instead of IEEE division
     int lds_prims = 1;                       // tiny scenes: primitive records in LDS; 1 = shadow kernel only, 2 = extend too
     int device_build = 1;                    // hierarchies and leaf-order records are made on the GPU (rt_set_option)
+    int motion_boxes = 1;                    // device-built hierarchies of scenes with moving primitives keep boxes per time
+    int sub_stride = 4;                      // words (float4) per second-level node: 4, or 8 with boxes per time
     bool built_on_device = false;            // what the current scene's upload used
     long long n_file_nodes = 0, n_file_entries = 0;
     int file_sub_depth = 0;                  // depth of the file-order hierarchy
@@ -359,6 +361,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     }
     if (std::strcmp(name, "lds_prims") == 0) { c->lds_prims = (int)value; return RT_OK; }
     if (std::strcmp(name, "device_build") == 0) { c->device_build = value != 0; return RT_OK; }
+    if (std::strcmp(name, "motion_boxes") == 0) { c->motion_boxes = value != 0; return RT_OK; }
     if (std::strcmp(name, "graphs") == 0) { c->use_graphs = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "max_grid") == 0) {
         if (value < 0 || value > (1 << 20)) return c->fail(RT_ERR_ARG, "max_grid must be 0..%d", 1 << 20);
@@ -421,7 +424,7 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
     c->built_on_device = on_device;
 
     std::vector<float4> mats((size_t)(np + nc + ns) * 3);
-    std::atomic<int> any_refl{ 0 }, any_transp{ 0 }, bad_tex{ -1 }, bad_plane{ -1 };
+    std::atomic<int> any_refl{ 0 }, any_transp{ 0 }, any_moving{ 0 }, bad_tex{ -1 }, bad_plane{ -1 };
     auto put_mat = [&](int gid, const rt_material& m) -> bool {
         if (m.tex_id >= sc->n_textures) { bad_tex = gid; return false; }
         // raytracer.cpp:374-375: mean specular times 0.5 (the 0.5 is a double literal; the product is exact), clamped
@@ -527,6 +530,7 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
             w[3] = f4(std::cos(q.rotation[2]), std::sin(q.rotation[2]), as_f(np + (int)i), 0.0f);
             w[4] = f4(std::cos(iz), std::sin(iz), std::cos(iy), std::sin(iy));
             w[5] = f4(std::cos(ix), std::sin(ix), 0.0f, 0.0f);
+            if (!(q.start[0] == q.end[0] && q.start[1] == q.end[1] && q.start[2] == q.end[2])) any_moving = 1;
             put_mat(np + (int)i, q.mat);
         }
     });
@@ -536,11 +540,15 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
             const rt_sphere& s = sc->spheres[i];
             c->h_file_spheres[i * 2 + 0] = f4(s.start[0], s.start[1], s.start[2], s.radius);
             c->h_file_spheres[i * 2 + 1] = f4(s.end[0], s.end[1], s.end[2], as_f(np + nc + (int)i));
+            if (!(s.start[0] == s.end[0] && s.start[1] == s.end[1] && s.start[2] == s.end[2])) any_moving = 1;
             put_mat(np + nc + (int)i, s.mat);
         }
     });
     if (bad_tex >= 0) return c->fail(RT_ERR_ARG, "primitive %d (planes, cubes, spheres in file order): texture id out of range", bad_tex.load());
     c->any_reflective = any_refl != 0; c->any_transparent = any_transp != 0;
+    // Hierarchies built on the device keep, for scenes in which something moves, boxes per time instead of boxes over
+    // the whole motion (8 words per node instead of 4).
+    c->sub_stride = (on_device && any_moving != 0 && c->motion_boxes) ? 8 : 4;
 
     std::vector<float4> lights((size_t)sc->n_lights);
     for (int i = 0; i < sc->n_lights; ++i)
@@ -603,10 +611,10 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
         BuildGroup g{}; g.pn = np; g.cn = nc; g.sn = ns; g.n = np + nc + ns; g.depth = rt_build_depth(g.n);
         if (g.depth > RT_SUB_MAX_DEPTH) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_MAX_DEPTH);
         c->n_file_nodes = 1ll << g.depth; c->n_file_entries = 4ll << g.depth; c->file_sub_depth = g.depth;   // one node slot stays unused
-        RT_HIP(c, c->d_sub_nodes_file.resize((size_t)c->n_file_nodes * 4));
+        RT_HIP(c, c->d_sub_nodes_file.resize((size_t)c->n_file_nodes * (size_t)c->sub_stride));
         RT_HIP(c, c->d_sub_entries_file.resize((size_t)c->n_file_entries));
         float fin[6];
-        RT_HIP(c, rt_build_hierarchies(s, d.fileset, &g, 1, g.n, c->sphere_e, c->d_sub_nodes_file.p, c->d_sub_entries_file.p, fin));
+        RT_HIP(c, rt_build_hierarchies(s, d.fileset, &g, 1, g.n, c->sphere_e, c->sub_stride == 8, c->d_sub_nodes_file.p, c->d_sub_entries_file.p, fin));
         for (int k = 0; k < 3; ++k) { all.mn[k] = fin[k]; all.mx[k] = fin[3 + k]; }
         c->file_sub_root = 0;
         // the host copies of the records are only needed by the host build
@@ -658,7 +666,7 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
     d.lights = c->d_lights.p; d.n_lights = sc->n_lights;
     d.sub_nodes = c->n_file_nodes ? c->d_sub_nodes_file.p : nullptr;
     d.sub_entries = c->d_sub_entries_file.p; d.file_sub_root = c->file_sub_root;
-    d.file_sub_depth = c->file_sub_depth;
+    d.file_sub_depth = c->file_sub_depth; d.sub_stride = c->sub_stride;
     d.sub_stack_entries = d.sub_stack_entries_leaves = rt_sub_stack_entries(c->file_sub_depth);
     d.n_verts = sc->n_plane_verts;
     d.lds_prims = (!d.sub_nodes && rt_lds_prim_words(d) <= RT_LDS_PRIM_MAX_WORDS) ? c->lds_prims : 0;
@@ -792,10 +800,11 @@ static int upload_bvh_impl(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes,
         }
         total_entries = 4 * total_nodes;                                  // four entry slots per run, at 4 * (node_base + run)
         if (total_nodes > 0x7fffffffll / 4 || total_entries > 0x7fffffffll) return c->fail(RT_ERR_CAPACITY, "second-level hierarchies too large");
-        RT_HIP(c, c->d_sub_nodes.resize((size_t)total_nodes * 4)); RT_HIP(c, c->d_sub_entries.resize((size_t)total_entries));
-        if (c->n_file_nodes) RT_HIP(c, hipMemcpyAsync(c->d_sub_nodes.p, c->d_sub_nodes_file.p, sizeof(float4) * 4 * (size_t)c->n_file_nodes, hipMemcpyDeviceToDevice, s));
+        const size_t stride = (size_t)c->sub_stride;
+        RT_HIP(c, c->d_sub_nodes.resize((size_t)total_nodes * stride)); RT_HIP(c, c->d_sub_entries.resize((size_t)total_entries));
+        if (c->n_file_nodes) RT_HIP(c, hipMemcpyAsync(c->d_sub_nodes.p, c->d_sub_nodes_file.p, sizeof(float4) * stride * (size_t)c->n_file_nodes, hipMemcpyDeviceToDevice, s));
         if (c->n_file_entries) RT_HIP(c, hipMemcpyAsync(c->d_sub_entries.p, c->d_sub_entries_file.p, sizeof(int) * (size_t)c->n_file_entries, hipMemcpyDeviceToDevice, s));
-        RT_HIP(c, rt_build_hierarchies(s, leafset, groups.data(), (int)groups.size(), n_items, c->sphere_e,
+        RT_HIP(c, rt_build_hierarchies(s, leafset, groups.data(), (int)groups.size(), n_items, c->sphere_e, c->sub_stride == 8,
                                        c->d_sub_nodes.p, c->d_sub_entries.p, nullptr));
     } else {
         std::vector<float4> lp, lc, ls;

@@ -390,6 +390,8 @@ DEVI bool test_prims(const DevPrimSet& S, const Ray& r, bool mb, int p0, int pn,
 //     direction component below 1e-5 as zero, which moves the reported point by up to 1e-5 x distance).
 // An interior node holds both children's boxes: (minL, refL) (maxL, cntL) (minR, refR) (maxR, cntR); ref >= 0 is an
 // interior node, ref < 0 a run of cnt entries starting at ~ref (a multiple of four).  entry = class << 30 | index in the set.
+// In scenes with moving primitives those are the boxes at time 0, and four more words per node hold how far each corner
+// moves until time 1: primitives move on straight lines, so the interpolated box bounds them at the ray's time.
 // ---------------------------------------------------------------------------------------------------------
 // Per-ray constants of the second-level walk.  A box is entered at max over axes of (near plane - origin) / d and left
 // at min over axes of (far plane - origin) / d; which plane is the near one depends only on the sign of d, and with
@@ -449,25 +451,46 @@ DEVI void sub_child(const SubRay& q, float4 mn, float4 mx, float& tn, float& tf)
 // its two children) it loads the records of both children (128 contiguous bytes, address known from the heap index
 // alone) and tests the four grandchildren - half as many dependent round trips to memory per ray.  All children of a
 // step are of one kind: interior nodes, or (below level depth - 2) runs.
-template <bool ANY, bool FAST>
+template <bool ANY, bool FAST, bool MOTION>
 DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth, const Ray& r, const SubRay& q, bool mb, bool leaf_rule,
                     float stop_below, int* __restrict__ stack, Best& best) {
     float best_t = leaf_rule ? INFINITY : FLT_MAX;
     unsigned best_key = 0u; bool has = false;
     int sp = 0, h = 0;                                        // h = heap index inside the group
+    // Scenes with moving primitives keep boxes per time (8 words per node); rays at time 0 - every secondary ray, and
+    // every ray of a frame without motion blur, where primitives stay at their first location - read the first half only.
+    const float tm = (MOTION && mb) ? r.time : 0.0f;
+    const float4* __restrict__ base = sc.sub_nodes + (size_t)(MOTION ? 8 : 4) * (size_t)root;
     const int first_run = (1 << depth) - 1;                   // heap index the first run would have
     for (;;) {
         const int level = 31 - __clz(h + 1);
         const bool wide = level + 2 <= depth;                 // the children are interior nodes: step to the grandchildren
         const bool runs = level + 2 >= depth;                 // what this step tests are runs of entries
         const int kid0 = wide ? 4 * h + 3 : 2 * h + 1;        // heap index of the first child tested
-        const float4* __restrict__ nd = sc.sub_nodes + 4 * (size_t)(root + (wide ? 2 * h + 1 : h));
+        // first word of the record(s) read: node h itself, or (wide) its two children, which are neighbours
+        const int first = wide ? 2 * h + 1 : h;
+        const float4* __restrict__ nd = base + (MOTION ? (unsigned)rt_sub_motion_offset(first) : 4u * (unsigned)first);
         float4 bx[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) bx[k] = nd[k];
         if (wide) {
 #pragma unroll
             for (int k = 4; k < 8; ++k) bx[k] = nd[k];
+        }
+        if (MOTION && tm != 0.0f) {
+            // boxes per time: corners at time 0 plus time x (their change until time 1)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 dl = nd[8 + k];
+                bx[k].x = __builtin_fmaf(dl.x, tm, bx[k].x); bx[k].y = __builtin_fmaf(dl.y, tm, bx[k].y); bx[k].z = __builtin_fmaf(dl.z, tm, bx[k].z);
+            }
+            if (wide) {
+#pragma unroll
+                for (int k = 4; k < 8; ++k) {
+                    const float4 dl = nd[8 + k];
+                    bx[k].x = __builtin_fmaf(dl.x, tm, bx[k].x); bx[k].y = __builtin_fmaf(dl.y, tm, bx[k].y); bx[k].z = __builtin_fmaf(dl.z, tm, bx[k].z);
+                }
+            }
         }
         float tn4[4]; bool go4[4];
 #pragma unroll
@@ -529,11 +552,12 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth
 }
 
 // Closest hit of a group of primitives: through its second-level hierarchy when it has one, else one by one.
-// SUB = the scene has at least one second-level hierarchy (kernels for small scenes are compiled without that code).
-template <bool ANY, bool SUB, bool FAST>
+// SUB = the scene has at least one second-level hierarchy (kernels for small scenes are compiled without that code):
+// 1 = node records of 4 words, 2 = of 8 words (boxes per time, scenes with moving primitives).
+template <bool ANY, int SUB, bool FAST>
 DEVI bool test_group(const DevScene& sc, const DevPrimSet& S, const Ray& r, const SubRay& q, bool mb, int p0, int pn, int c0, int cn, int s0, int sn,
                      int sub_root, int sub_depth, bool leaf_rule, float stop_below, int* __restrict__ stack, Best& best) {
-    if (SUB && sub_root >= 0) return sub_trace<ANY, FAST>(sc, S, sub_root, sub_depth, r, q, mb, leaf_rule, stop_below, stack, best);
+    if (SUB && sub_root >= 0) return sub_trace<ANY, FAST, SUB == 2>(sc, S, sub_root, sub_depth, r, q, mb, leaf_rule, stop_below, stack, best);
     return test_prims<ANY, FAST>(S, r, mb, p0, pn, c0, cn, s0, sn, leaf_rule, stop_below, best);
 }
 
@@ -544,7 +568,7 @@ DEVI bool test_group(const DevScene& sc, const DevPrimSet& S, const Ray& r, cons
 // with_fallback: raytracer.cpp:424,484 - a secondary ray that misses the BVH is retried over every primitive.
 // stop_below (see test_prims) ends the search inside the one group whose result the reference would return: a leaf
 // that yields any hit ends the reference's walk too, so nothing is skipped that could change "closest < stop_below".
-template <bool ANY, bool SUB, bool FAST = false>
+template <bool ANY, int SUB, bool FAST = false>
 DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict__ nodes, const int4* __restrict__ leaves,
                 int* __restrict__ stack, const Ray& r, bool with_fallback, Best& best, float stop_below = -INFINITY) {
     const bool mb = f.motion_blur != 0;
@@ -705,7 +729,7 @@ DEVI bool generate_primary(const DevFrame& f, int i, Ray& r, uint32_t& path, int
 // reflection / refraction rays of the next level (raytracer.cpp:144-164 for primaries, :373-498 for the spawn).
 // ---------------------------------------------------------------------------------------------------------
 // STATS: the kernel keeps the six per-thread ray counts (twelve registers it otherwise has to spill)
-template <bool PRIMARY, bool SUB, bool LDSP, bool STATS>
+template <bool PRIMARY, int SUB, bool LDSP, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAVES) void k_extend(DevScene sc_arg, DevFrame f, DevWork w, int level) {
     extern __shared__ float4 s_mem[];
     DevScene sc = sc_arg;
@@ -996,7 +1020,7 @@ DEVI bool cone_may_hit(const DevScene& sc, bool mb, V3 p, V3 lc, float R) {
 // ---------------------------------------------------------------------------------------------------------
 // MODE: 0 = hard shadows, 1 = soft shadows in the reference's arithmetic, 2 = soft shadows on reciprocals (separate
 // kernels: each needs fewer registers than one kernel holding both searches, which decides how many wavefronts fit)
-template <bool SUB, bool LDSP, int MODE>
+template <int SUB, bool LDSP, int MODE>
 __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAVES) void k_shadow(DevScene sc_arg, DevFrame f, DevWork w, int lv_begin, int lv_end) {
     extern __shared__ float4 s_mem[];
     DevScene sc = sc_arg;
@@ -1046,7 +1070,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     const float4 light0 = sc.lights[0];                                 // count > 0 implies a light; the usual scene has one
 
     // One sample ray: hard shadows (raytracer.cpp:509-530) or sample j of a soft shadow (raytracer.cpp:534-571).
-    auto sample_unblocked = [&](int node, int l, int j, const float4 a, const float4 lt) -> bool {
+    auto sample_unblocked = [&](int node, int l, int j, const float4 a, const float4 lt) __attribute__((always_inline)) -> bool {
         const V3 p = mk(a.x, a.y, a.z);
         Ray sr; sr.time = a.w;
         Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
@@ -1390,14 +1414,17 @@ void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, cons
 #define RT_EXTEND_LAUNCH(PRIMARY, SUB, LDSP) \
     do { if (f.count_stats) hipLaunchKernelGGL((k_extend<PRIMARY, SUB, LDSP, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level); \
          else hipLaunchKernelGGL((k_extend<PRIMARY, SUB, LDSP, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level); } while (0)
+    const bool per_time = sc.sub_stride == 8;
     if (level == 0) {
-        if (sub) RT_EXTEND_LAUNCH(true, true, false);
-        else if (ldsp) RT_EXTEND_LAUNCH(true, false, true);
-        else RT_EXTEND_LAUNCH(true, false, false);
+        if (sub && per_time) RT_EXTEND_LAUNCH(true, 2, false);
+        else if (sub) RT_EXTEND_LAUNCH(true, 1, false);
+        else if (ldsp) RT_EXTEND_LAUNCH(true, 0, true);
+        else RT_EXTEND_LAUNCH(true, 0, false);
     } else {
-        if (sub) RT_EXTEND_LAUNCH(false, true, false);
-        else if (ldsp) RT_EXTEND_LAUNCH(false, false, true);
-        else RT_EXTEND_LAUNCH(false, false, false);
+        if (sub && per_time) RT_EXTEND_LAUNCH(false, 2, false);
+        else if (sub) RT_EXTEND_LAUNCH(false, 1, false);
+        else if (ldsp) RT_EXTEND_LAUNCH(false, 0, true);
+        else RT_EXTEND_LAUNCH(false, 0, false);
     }
 #undef RT_EXTEND_LAUNCH
 }
@@ -1409,9 +1436,10 @@ void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, cons
     do { if (mode == 2) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 2>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); \
          else if (mode == 1) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 1>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); \
          else hipLaunchKernelGGL((k_shadow<SUB, LDSP, 0>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); } while (0)
-    if (sc.sub_nodes) RT_SHADOW_LAUNCH(true, false);
-    else if (sc.lds_prims) RT_SHADOW_LAUNCH(false, true);
-    else RT_SHADOW_LAUNCH(false, false);
+    if (sc.sub_nodes && sc.sub_stride == 8) RT_SHADOW_LAUNCH(2, false);
+    else if (sc.sub_nodes) RT_SHADOW_LAUNCH(1, false);
+    else if (sc.lds_prims) RT_SHADOW_LAUNCH(0, true);
+    else RT_SHADOW_LAUNCH(0, false);
 #undef RT_SHADOW_LAUNCH
 }
 

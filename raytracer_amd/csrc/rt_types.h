@@ -6,6 +6,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Scenes with moving primitives, 8 words per second-level node: where node h (heap index inside its group) keeps its
+// time-0 words, relative to the group's first word; its motion words follow 8 words later.  The root has a block of 16
+// words to itself, after it two siblings share one: both time-0 records (one 128-byte line), then both motion records.
+__host__ __device__ inline size_t rt_sub_motion_offset(int h) {
+    return h ? 16 + 16 * (size_t)((h - 1) >> 1) + 4 * (size_t)((h - 1) & 1) : 0;
+}
+
 #define RT_TILE        32            // image tiles are RT_TILE x RT_TILE pixels; a wavefront covers two tile rows
 #define RT_TILE_PIX    (RT_TILE * RT_TILE)
 #define RT_BLOCK       256           // threads per workgroup = 4 wavefronts
@@ -65,6 +72,7 @@ struct DevScene {
     const int* sub_entries;
     int file_sub_root;             // second-level root over the whole file-order set, or -1
     int file_sub_depth;            // depth of that hierarchy
+    int sub_stride;                // words per second-level node: 4 (boxes over the whole motion) or 8 (boxes per time, see rt_sub_motion_offset)
     int sub_stack_entries;         // traversal stack entries per thread, see rt_sub_stack_entries: any hierarchy of the scene
     int sub_stack_entries_leaves;  // the same for walks that only enter the leaves' hierarchies (not the file-order set's)
     int n_verts;                   // polygon vertices of all planes

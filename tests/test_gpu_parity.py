@@ -304,6 +304,31 @@ def test_device_built_hierarchies_equal_host_built(n, flags):
     assert np.array_equal(got[0][0], got[1][0]) and got[0][1] == got[1][1]
 
 
+@pytest.mark.parametrize("n,flags", [(20000, ["-m", "-mbs", "4"]), (20000, ["-m", "-mbs", "2", "-r", "-rd", "2", "-ss", "-sss", "4"]),
+                                     (20000, ["-m", "-mbs", "2", "-u"]), (20000, []), (30000, ["-m", "-mbs", "2", "-r", "-gr", "-grs", "2", "-rd", "2"])])
+def test_boxes_per_time_change_no_pixel(n, flags):
+    """Scenes in which primitives move keep, in the second-level hierarchies, boxes at time 0 and their change until
+    time 1 instead of boxes over the whole motion.  Either kind of box only decides what a ray may skip: frames and ray
+    counts are identical with the option off, and identical to testing every primitive of a group one by one."""
+    table = sg.random_prims(n, 11, transparent_frac=0.1, moving=True)
+    cfg, _ = api.parse_args(flags)
+    got = []
+    for motion_boxes, min_group in ((1, 8), (0, 8), (1, 1 << 40)):
+        if min_group > 8 and n > 20000:
+            continue
+        ls = api.ArrayScene(table, (480, 270), moving=True)
+        r = api.Renderer(0)
+        r.set_option("motion_boxes", motion_boxes)
+        r.set_option("second_level_min_group", min_group)
+        r.upload(ls, with_bvh=bool(cfg.bvh))
+        img, st = r.render(cfg)
+        got.append((img, (st.shadow_rays, st.reflection_rays, st.refraction_rays)))
+        r.close(); ls.close()
+    assert got[0][0].max() > 0
+    for other in got[1:]:
+        assert np.array_equal(got[0][0], other[0]) and got[0][1] == other[1]
+
+
 def test_large_scene_windows_match_oracle():
     """50 000 primitives at 1920x1080: the whole frame is out of the oracle's reach, pixel windows are not."""
     n, res = 50000, (1920, 1080)
