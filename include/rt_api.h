@@ -191,7 +191,9 @@ void* rt_get_stream(rt_ctx* ctx);
  * depth-8 tree, or the whole scene for -u) are searched through a second-level hierarchy instead of one by
  * one; default 8, a huge value turns the hierarchy off.  "device_build" = 0/1: whether those hierarchies and the
  * leaf-order copies of the primitive records are made by kernels on the device (default 1) or on the host; set
- * before rt_upload_scene.  "graphs" = 0/1: whether rt_render_device (without
+ * before rt_upload_scene.  "motion_boxes" = 0/1 (default 1, before rt_upload_scene): device-built hierarchies of a scene in
+ * which a sphere or cube moves keep boxes per time (at time 0 and their change until time 1, 128 bytes per node)
+ * instead of boxes over the whole motion (64 bytes per node).  "graphs" = 0/1: whether rt_render_device (without
  * statistics) records a frame's launch sequence into a HIP graph on its second call with the same configuration,
  * output pointer and stream, and replays it afterwards; default 1.  "overlap" = 0/1: whether frames rendered
  * without statistics trace the shadow rays of the primary hits on a second, internal stream while the render
