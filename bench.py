@@ -241,6 +241,7 @@ def copy_ceiling_GBps(torch, dev) -> float:
 
 def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps: int, warmup: int, frames_in_flight: int, detail: bool) -> dict | None:
     """Uploads the workload on every rank, times `steps` frames, returns rank 0's result dictionary."""
+    import numpy as np
     import torch
     import torch.distributed as dist
     import cases
@@ -396,6 +397,18 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     for _ in range(n_lat):
         r.render_device(cfg, block.data_ptr()); r.synchronize()
     frame_latency_ms = (time.perf_counter() - t_lat) * 1000.0 / n_lat
+    # the same frame through rt_render (waits, copies the image to the host): into page-locked memory from
+    # rt_alloc_image and into an ordinary array.  Reported, never `value`.
+    to_host = None
+    if detail and world == 1 and not heavy:
+        to_host = {}
+        for kind, buf in (("page_locked", api.image_buffer(r.out_bytes())), ("pageable", np.zeros(r.out_bytes(), dtype=np.uint8))):
+            r.render(cfg, out=buf, want_stats=False)
+            t_h = time.perf_counter()
+            for _ in range(n_lat):
+                r.render(cfg, out=buf, want_stats=False)
+            to_host[kind] = (time.perf_counter() - t_h) * 1000.0 / n_lat
+        del buf
     # every context records a frame graph on its second frame with the same output buffer; a pipeline alternates
     # between two blocks, so it needs four frames before both graphs exist
     warm_steps = warmup if heavy else max(warmup, (4 if pipelined else 2) * P)
@@ -426,7 +439,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
         lit = float((final.reshape(-1, 3).sum(axis=1) > 0).mean())
         res = {"workload": describe(name), "value": rays_total / (elapsed / steps), "ms_per_step": 1000.0 * elapsed / steps,
                "steps": steps, "warmup": warm_steps, "spp": spp, "frames_in_flight": P, "frame_ms_alone": frame_latency_ms,
-               "host_enqueue_ms_per_step": 1000.0 * t_enq / steps, "upload_seconds": upload_s,
+               "frame_ms_to_host": to_host, "host_enqueue_ms_per_step": 1000.0 * t_enq / steps, "upload_seconds": upload_s,
                "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3],
                                   "hits_shaded": tot[5], "as_the_reference_would_trace_them": tot[0] + tot[4],
                                   "shadow_not_traced_because_the_surface_faces_away_from_the_light":
@@ -524,6 +537,7 @@ def main():
             "config": {"workload": head["workload"], "spp": head["spp"], "tiles": "32x32 interleaved, rank = (tx+ty) % N",
                        "frames_in_flight": head["frames_in_flight"], "frame_ms_alone": head["frame_ms_alone"],
                        "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
+                       "frame_ms_to_host": head.get("frame_ms_to_host"),
                        "timing": "ms_per_step = timed wall clock / steps with frames_in_flight independent frames overlapping on the GPU; "
                                  "frame_ms_alone = one frame enqueued and waited for by itself",
                        "soft_shadow_sampling": "the first reflection of every path is recorded gr_samples times (each copy draws its own shadow "

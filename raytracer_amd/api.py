@@ -113,6 +113,7 @@ class HostBvh(C.Structure):
 API_SYMBOLS = ["rt_default_config", "rt_create", "rt_destroy", "rt_set_stream", "rt_get_stream", "rt_set_option", "rt_upload_scene", "rt_upload_bvh",
                "rt_set_shard", "rt_local_tiles", "rt_max_tiles_per_rank", "rt_render", "rt_render_device",
                "rt_assemble_tiles", "rt_synchronize", "rt_last_error", "rt_render_device_noalloc", "rt_noalloc_capacity",
+               "rt_alloc_image", "rt_free_image",
                "rt_multi_create", "rt_multi_destroy", "rt_multi_set_option", "rt_multi_upload", "rt_multi_render", "rt_multi_render_device",
                "rt_multi_synchronize", "rt_multi_image", "rt_multi_context", "rt_multi_uses_rccl", "rt_multi_last_error"]
 HOST_SYMBOLS = ["rt_host_parse_args", "rt_host_parse_scene", "rt_host_load_scene", "rt_host_free_scene",
@@ -120,6 +121,19 @@ HOST_SYMBOLS = ["rt_host_parse_args", "rt_host_parse_scene", "rt_host_load_scene
                 "rt_host_camera_ray"]
 
 _lib = None
+
+
+def image_buffer(n_bytes: int) -> np.ndarray:
+    """A flat uint8 array in page-locked host memory (rt_alloc_image), freed with the array: rt_render copies a frame
+    into it by one DMA transfer."""
+    import weakref
+    p = lib().rt_alloc_image(int(n_bytes))
+    if not p:
+        raise MemoryError(f"rt_alloc_image({n_bytes}) failed")
+    buf = (C.c_uint8 * int(n_bytes)).from_address(p)
+    arr = np.frombuffer(buf, dtype=np.uint8)
+    weakref.finalize(buf, lib().rt_free_image, p)
+    return arr
 
 
 def lib():
@@ -146,6 +160,8 @@ def lib():
     L.rt_assemble_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.rt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(Config), C.c_void_p]
     L.rt_noalloc_capacity.argtypes = []; L.rt_noalloc_capacity.restype = C.c_uint64
+    L.rt_alloc_image.argtypes = [C.c_uint64]; L.rt_alloc_image.restype = C.c_void_p
+    L.rt_free_image.argtypes = [C.c_void_p]; L.rt_free_image.restype = None
     L.rt_multi_create.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.c_uint64]; L.rt_multi_create.restype = C.c_void_p
     L.rt_multi_destroy.argtypes = [C.c_void_p]; L.rt_multi_destroy.restype = None
     L.rt_multi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
@@ -486,11 +502,15 @@ class Renderer:
             return self.max_tiles_per_rank * TILE * TILE * 3
         return self.width * self.height * 3
 
-    def render(self, cfg: Config) -> tuple[np.ndarray, Stats]:
-        """rt_render: result copied to host. world == 1 -> [H,W,3] uint8; else the flat tile-major block."""
-        out = np.zeros(self.out_bytes(), dtype=np.uint8)
-        st = Stats()
-        self._check(lib().rt_render(self._ctx, C.byref(cfg), out.ctypes.data_as(C.c_void_p), C.byref(st)))
+    def render(self, cfg: Config, out: np.ndarray | None = None, want_stats: bool = True) -> tuple[np.ndarray, Stats | None]:
+        """rt_render: result copied to host. world == 1 -> [H,W,3] uint8; else the flat tile-major block.
+        out: a flat uint8 array of out_bytes() to render into (e.g. from image_buffer()); default a new array."""
+        if out is None:
+            out = np.zeros(self.out_bytes(), dtype=np.uint8)
+        elif out.dtype != np.uint8 or out.size != self.out_bytes() or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError(f"out must be a contiguous uint8 array of {self.out_bytes()} bytes")
+        st = Stats() if want_stats else None
+        self._check(lib().rt_render(self._ctx, C.byref(cfg), out.ctypes.data_as(C.c_void_p), C.byref(st) if st else None))
         if self.world == 1:
             out = out.reshape(self.height, self.width, 3)
         return out, st

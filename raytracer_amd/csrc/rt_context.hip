@@ -1327,13 +1327,21 @@ int rt_render(rt_ctx* c, const rt_config* cfg, uint8_t* rgb_out, rt_stats* stats
     if (bytes > c->out_tmp.n) { RT_HIP(c, hipStreamSynchronize(c->stream)); RT_HIP(c, c->out_tmp.resize(bytes)); }
     auto t0 = std::chrono::steady_clock::now();
     StageTimer tm; tm.on = stats != nullptr; tm.pool = &c->event_pool;
-    int rc = enqueue_frame(c, cfg, c->out_tmp.p, true, &tm);
+    int rc = enqueue_frame(c, cfg, c->out_tmp.p, true, &tm, stats != nullptr && c->count_rays);
     if (rc != RT_OK) { double sm[ST_COUNT]; (void)hipStreamSynchronize(c->stream); tm.collect(sm); return rc; }
     RT_HIP(c, hipStreamSynchronize(c->stream));
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     RT_HIP(c, hipMemcpy(rgb_out, c->out_tmp.p, bytes, hipMemcpyDeviceToHost));
     return finish_stats(c, stats, ms, &tm);
 }
+
+void* rt_alloc_image(uint64_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void rt_free_image(void* p) { if (p) (void)hipHostFree(p); }
 
 int rt_assemble_tiles(rt_ctx* c, const void* tiles_dev, int32_t world, void* rgb_out_dev) {
     if (!c || !tiles_dev || !rgb_out_dev || world < 1) return RT_ERR_ARG;

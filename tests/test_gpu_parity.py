@@ -329,6 +329,27 @@ def test_boxes_per_time_change_no_pixel(n, flags):
         assert np.array_equal(got[0][0], other[0]) and got[0][1] == other[1]
 
 
+def test_render_into_page_locked_memory():
+    """rt_render into memory from rt_alloc_image gives the image it gives into an ordinary array, with and without
+    statistics, and the buffer outlives the call that filled it."""
+    ls = api.LoadedScene(cases.reference_scene(320, 180), api.parse_args([])[0], str(cases.TEXTURES))
+    cfg, _ = api.parse_args(["-r", "-rd", "2"])
+    r = api.Renderer(0)
+    r.upload(ls, with_bvh=True)
+    want, st = r.render(cfg)
+    buf = api.image_buffer(r.out_bytes())
+    buf[:] = 7
+    got, st2 = r.render(cfg, out=buf)
+    assert np.array_equal(got, want) and st2.shadow_rays == st.shadow_rays
+    buf[:] = 7
+    got, none = r.render(cfg, out=buf, want_stats=False)
+    assert none is None and np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        r.render(cfg, out=np.zeros(5, dtype=np.uint8))
+    r.close(); ls.close()
+    assert np.array_equal(got, want)
+
+
 def test_large_scene_windows_match_oracle():
     """50 000 primitives at 1920x1080: the whole frame is out of the oracle's reach, pixel windows are not."""
     n, res = 50000, (1920, 1080)
