@@ -411,9 +411,14 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
         del buf
     # every context records a frame graph on its second frame with the same output buffer; a pipeline alternates
     # between two blocks, so it needs four frames before both graphs exist
-    warm_steps = warmup if heavy else max(warmup, (4 if pipelined else 2) * P)
-    note(f"one frame alone {frame_latency_ms:.2f} ms; warming up ({warm_steps}) and timing {steps} steps")
-    for _ in range(warm_steps):
+    # Part of the set-up, not of the warm-up: these frames make every context record its graph(s).  Then exactly `warmup`
+    # untimed steps and `steps` timed ones.
+    prime_steps = 0 if heavy else (4 if pipelined else 2) * P
+    note(f"one frame alone {frame_latency_ms:.2f} ms; {prime_steps} frames to record the frame graphs, warming up ({warmup}) and timing {steps} steps")
+    for _ in range(prime_steps):
+        step()
+    torch.cuda.synchronize(dev)
+    for _ in range(warmup):
         step()
     if world > 1:
         dist.barrier()
@@ -438,7 +443,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
         final = ((pipes[last].image if pipelined else image) if world > 1 else ctxs[last][2]).cpu().numpy()
         lit = float((final.reshape(-1, 3).sum(axis=1) > 0).mean())
         res = {"workload": describe(name), "value": rays_total / (elapsed / steps), "ms_per_step": 1000.0 * elapsed / steps,
-               "steps": steps, "warmup": warm_steps, "spp": spp, "frames_in_flight": P, "frame_ms_alone": frame_latency_ms,
+               "steps": steps, "warmup": warmup, "graph_recording_frames": prime_steps, "spp": spp, "frames_in_flight": P, "frame_ms_alone": frame_latency_ms,
                "frame_ms_to_host": to_host, "host_enqueue_ms_per_step": 1000.0 * t_enq / steps, "upload_seconds": upload_s,
                "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3],
                                   "hits_shaded": tot[5], "as_the_reference_would_trace_them": tot[0] + tot[4],
@@ -537,6 +542,7 @@ def main():
             "config": {"workload": head["workload"], "spp": head["spp"], "tiles": "32x32 interleaved, rank = (tx+ty) % N",
                        "frames_in_flight": head["frames_in_flight"], "frame_ms_alone": head["frame_ms_alone"],
                        "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
+                       "graph_recording_frames_before_warmup": head["graph_recording_frames"],
                        "frame_ms_to_host": head.get("frame_ms_to_host"),
                        "timing": "ms_per_step = timed wall clock / steps with frames_in_flight independent frames overlapping on the GPU; "
                                  "frame_ms_alone = one frame enqueued and waited for by itself",
