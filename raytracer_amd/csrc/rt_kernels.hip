@@ -663,6 +663,11 @@ DEVI void block_stat_add(unsigned long long* stat, unsigned long long v, unsigne
     }
 }
 
+// Pixel of slot `in` (0 .. RT_TILE_PIX - 1) inside its tile: the 64 slots of a wavefront cover an 8 x 8 block of pixels
+// (blocks in row-major order), not two rows of 32 - neighbouring rays, hence neighbouring walks through large scenes.
+DEVI int slot_col(int in) { return (((in >> 6) & 3) << 3) | (in & 7); }
+DEVI int slot_row(int in) { return ((in >> 8) << 3) | ((in >> 3) & 7); }
+
 // Camera::convertPixelToRay (camera.cpp:109-199) and the sample loops around it (raytracer.cpp:120-141).
 // i = index inside the batch; one batch = one sample index for a range of this rank's pixel slots.
 DEVI bool generate_primary(const DevFrame& f, int i, Ray& r, uint32_t& path, int& slot) {
@@ -671,8 +676,8 @@ DEVI bool generate_primary(const DevFrame& f, int i, Ray& r, uint32_t& path, int
     // a wavefront's 64 slots lie in one tile (batches start at multiples of 64): one scalar load, which does not
     // queue behind the vector stores of the previous round
     int gt = f.local_tiles[__builtin_amdgcn_readfirstlane(tile_local)];
-    int x = (gt % f.tiles_x) * RT_TILE + (in % RT_TILE);
-    int y = (gt / f.tiles_x) * RT_TILE + (in / RT_TILE);
+    int x = (gt % f.tiles_x) * RT_TILE + slot_col(in);
+    int y = (gt / f.tiles_x) * RT_TILE + slot_row(in);
     if (x >= f.width || y >= f.height) return false;
     uint32_t pixel = (uint32_t)(y * f.width + x);
     int s = f.sample;
@@ -1193,12 +1198,14 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
 // this rank's tile-major block).  A wavefront's slots that reach here together lie in one tile only in k_finalize.
 DEVI void store_pixel(const DevFrame& f, unsigned char* __restrict__ out, int tile_major, int slot, float cr, float cg, float cb) {
     int r = (int)(255.0f * cr), g = (int)(255.0f * cg), b = (int)(255.0f * cb);
+    const int tile_local = slot / RT_TILE_PIX, in = slot % RT_TILE_PIX;
     if (tile_major) {
-        out[3 * slot] = (unsigned char)r; out[3 * slot + 1] = (unsigned char)g; out[3 * slot + 2] = (unsigned char)b;
+        // a rank's block holds its tiles one after the other, each row-major
+        const int o = 3 * (tile_local * RT_TILE_PIX + slot_row(in) * RT_TILE + slot_col(in));
+        out[o] = (unsigned char)r; out[o + 1] = (unsigned char)g; out[o + 2] = (unsigned char)b;
     } else {
-        int tile_local = slot / RT_TILE_PIX, in = slot % RT_TILE_PIX;
         int gt = f.local_tiles[tile_local];
-        int x = (gt % f.tiles_x) * RT_TILE + (in % RT_TILE), y = (gt / f.tiles_x) * RT_TILE + (in / RT_TILE);
+        int x = (gt % f.tiles_x) * RT_TILE + slot_col(in), y = (gt / f.tiles_x) * RT_TILE + slot_row(in);
         if (x < f.width && y < f.height) {
             size_t o = ((size_t)y * f.width + x) * 3;
             out[o] = (unsigned char)r; out[o + 1] = (unsigned char)g; out[o + 2] = (unsigned char)b;
