@@ -290,6 +290,9 @@ class ArrayScene(LoadedScene):
             arr["start"] = rows[:, 0:3]; arr["end"] = rows[:, 0:3]
             if moving:
                 arr["end"][:, 2] = (rows[:, 2] + rows[:, 8]).astype(np.float32)
+            if moving == "xyz":                                  # not only upwards (tests)
+                arr["end"][:, 0] = (rows[:, 0] + 0.7 * rows[:, 8]).astype(np.float32)
+                arr["end"][:, 1] = (rows[:, 1] - 0.4 * rows[:, 8]).astype(np.float32)
             mats(rows, arr)
         self._s["radius"] = sph[:, 3]; self._c["scale"] = cub[:, 3]; self._c["rotation"] = cub[:, 9:12]
         self._lights = (Light * 1)(); self._lights[0].location[:] = sg.REF_LIGHT; self._lights[0].rad_intensity = 1000.0

@@ -304,9 +304,10 @@ def test_device_built_hierarchies_equal_host_built(n, flags):
     assert np.array_equal(got[0][0], got[1][0]) and got[0][1] == got[1][1]
 
 
-@pytest.mark.parametrize("n,flags", [(20000, ["-m", "-mbs", "4"]), (20000, ["-m", "-mbs", "2", "-r", "-rd", "2", "-ss", "-sss", "4"]),
-                                     (20000, ["-m", "-mbs", "2", "-u"]), (20000, []), (30000, ["-m", "-mbs", "2", "-r", "-gr", "-grs", "2", "-rd", "2"])])
-def test_boxes_per_time_change_no_pixel(n, flags):
+@pytest.mark.parametrize("n,flags,moving", [(20000, ["-m", "-mbs", "4"], True), (20000, ["-m", "-mbs", "2", "-r", "-rd", "2", "-ss", "-sss", "4"], "xyz"),
+                                            (20000, ["-m", "-mbs", "2", "-u"], "xyz"), (20000, [], True), (20000, ["-m", "-mbs", "3"], "xyz"),
+                                            (30000, ["-m", "-mbs", "2", "-r", "-gr", "-grs", "2", "-rd", "2"], True)])
+def test_boxes_per_time_change_no_pixel(n, flags, moving):
     """Scenes in which primitives move keep, in the second-level hierarchies, boxes at time 0 and their change until
     time 1 instead of boxes over the whole motion.  Either kind of box only decides what a ray may skip: frames and ray
     counts are identical with the option off, and identical to testing every primitive of a group one by one."""
@@ -316,7 +317,7 @@ def test_boxes_per_time_change_no_pixel(n, flags):
     for motion_boxes, min_group in ((1, 8), (0, 8), (1, 1 << 40)):
         if min_group > 8 and n > 20000:
             continue
-        ls = api.ArrayScene(table, (480, 270), moving=True)
+        ls = api.ArrayScene(table, (480, 270), moving=moving)
         r = api.Renderer(0)
         r.set_option("motion_boxes", motion_boxes)
         r.set_option("second_level_min_group", min_group)
@@ -350,12 +351,15 @@ def test_render_into_page_locked_memory():
     assert np.array_equal(got, want)
 
 
-def test_large_scene_windows_match_oracle():
-    """50 000 primitives at 1920x1080: the whole frame is out of the oracle's reach, pixel windows are not."""
+@pytest.mark.parametrize("moving", [False, True])
+def test_large_scene_windows_match_oracle(moving):
+    """50 000 primitives at 1920x1080: the whole frame is out of the oracle's reach, pixel windows are not.
+    moving: every primitive has a second location (hierarchies with boxes per time); without -m the reference renders
+    them at their first one, with recursion the secondary rays and their shadow rays walk those hierarchies too."""
     n, res = 50000, (1920, 1080)
-    text = sg.random_scene(n, 42, res)
-    ls = api.ArrayScene(sg.random_prims(n, 42), res)
-    for flags in ([], ["-u"]):
+    text = sg.random_scene(n, 42, res, moving=moving)
+    ls = api.ArrayScene(sg.random_prims(n, 42, moving=moving), res, moving=moving)
+    for flags in ([], ["-u"]) + ((["-rd", "2", "-grs", "1"],) if moving else ()):
         cfg, _ = api.parse_args(flags)
         r = api.Renderer(0); r.upload(ls, with_bvh=bool(cfg.bvh))
         img, _ = r.render(cfg); r.close()
