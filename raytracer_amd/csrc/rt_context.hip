@@ -935,38 +935,42 @@ struct WorkPlan {
     long long B = 0;                       // pixel slots per batch
     bool fanout = false, grouped = true;
     long long node_off[RT_MAX_LEVELS + 2], link_off[RT_MAX_LEVELS + 2], rcap[RT_MAX_LEVELS + 2];
-    size_t cap_nodes = 0, cap_links = 0, cap_rays = 0, cap_pix = 0, cap_shadow = 0;
+    long long slot_off[RT_MAX_LEVELS + 2], slot_mul[RT_MAX_LEVELS + 2];    // per-copy data (colours, shadow counts), see rt_types.h
+    size_t cap_nodes = 0, cap_slots = 0, cap_links = 0, cap_rays = 0, cap_pix = 0, cap_shadow = 0;
     long long widest_chunks[RT_MAX_LEVELS + 2];
 };
 
 // bytes of the per-batch buffers of a plan, each rounded up to 256
 static size_t plan_bytes(const WorkPlan& p, bool textures) {
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return 4 * al(p.cap_rays * 16) + 4 * al(p.cap_nodes * 16) + (textures ? al(p.cap_nodes * 8) : 0) + al(p.cap_pix * 4) +
+    return 4 * al(p.cap_rays * 16) + 3 * al(p.cap_nodes * 16) + al(p.cap_slots * 16) + (textures ? al(p.cap_nodes * 8) : 0) + al(p.cap_pix * 4) +
            al(p.cap_shadow * 4) + al(p.cap_links * 4);
 }
 
 static int make_plan(rt_ctx* c, const rt_config* cfg, int D, int L, bool textures, long long n_slots, unsigned long long budget, WorkPlan& p) {
     const long long gr = cfg->gr_samples;
     const long long refl = c->any_reflective ? 1 : 0, transp = c->any_transparent ? 1 : 0;
-    double npp[RT_MAX_LEVELS + 2];         // worst-case hits per primary sample at level d
+    double npp[RT_MAX_LEVELS + 2];         // worst-case nodes per primary sample at level d
+    double spn[RT_MAX_LEVELS + 2];         // slots per node of level d
     {
         double a = 1.0, b = 0.0;           // hits whose path has / has not yet had its gr_samples-fold reflection
         const bool replicate = cfg->soft_shadows && !cfg->glossy_reflect && c->replicate_reflections;
+        const bool bundle = replicate && gr <= 4096 && c->bundle_reflections;      // as DevFrame::bundle in enqueue_frame
         for (int d = 0; d <= D; ++d) {
-            npp[d] = a + b;
+            npp[d] = a + b; spn[d] = 1.0;
             if (cfg->glossy_reflect) { a = a * (double)(refl * gr + transp); }
+            else if (bundle) { a = a * (double)(refl + transp); if (d >= 1) spn[d] = (double)gr; }     // one node per traced ray
             else if (replicate) { const double a2 = a * (double)transp, b2 = a * (double)(refl * gr) + b * (double)(refl + transp); a = a2; b = b2; }
             else { a = a * (double)(refl + transp); }
         }
     }
     p.D = D;
     p.fanout = D > 0 && (refl || transp);
-    double nodes_per = 0, widest = 1;
-    for (int d = 0; d <= D; ++d) { nodes_per += npp[d]; widest = std::max(widest, npp[d]); if (!p.fanout) break; }
+    double nodes_per = 0, slots_per = 0, widest = 1;
+    for (int d = 0; d <= D; ++d) { nodes_per += npp[d]; slots_per += npp[d] * spn[d]; widest = std::max(widest, npp[d]); if (!p.fanout) break; }
     const double links_per = nodes_per - 1.0;
     p.grouped = !cfg->soft_shadows || (cfg->ss_samples <= 64 && (cfg->ss_samples & (cfg->ss_samples - 1)) == 0);
-    const double bytes_per = nodes_per * (16.0 * 4 + (textures ? 8 : 0) + 4.0 * std::max(L, 1)) + 4.0 + links_per * 4.0 +
+    const double bytes_per = nodes_per * (16.0 * 3 + (textures ? 8 : 0)) + slots_per * (16.0 + 4.0 * std::max(L, 1)) + 4.0 + links_per * 4.0 +
                              (p.fanout ? 2.0 * widest * 32.0 : 0.0);
     // (1/64 of the budget covers the rounding of the regions' capacities, see below)
     long long B = (long long)((double)budget * (63.0 / 64.0) / bytes_per);
@@ -985,23 +989,28 @@ static int make_plan(rt_ctx* c, const rt_config* cfg, int D, int L, bool texture
         long long widest_rcap = 0;
         const long long rcap0 = ((chunks0 + R - 1) / R) * RT_BLOCK;
         std::memset(p.node_off, 0, sizeof p.node_off); std::memset(p.link_off, 0, sizeof p.link_off); std::memset(p.rcap, 0, sizeof p.rcap);
+        std::memset(p.slot_off, 0, sizeof p.slot_off);
+        for (int d = 0; d < RT_MAX_LEVELS + 2; ++d) p.slot_mul[d] = 1;
         for (int d = 0; d <= D; ++d) {
             p.rcap[d] = (long long)((double)rcap0 * (p.fanout || d == 0 ? npp[d] : 0.0)) + (d ? 64 : 0);
             p.node_off[d + 1] = p.node_off[d] + R * p.rcap[d];
+            p.slot_mul[d] = (long long)spn[d];
+            p.slot_off[d + 1] = p.slot_off[d] + R * p.rcap[d] * p.slot_mul[d];
             if (d >= 1) { p.link_off[d + 1] = p.link_off[d] + R * p.rcap[d]; widest_rcap = std::max(widest_rcap, p.rcap[d]); }
         }
         p.link_off[D + 2] = p.link_off[D + 1];
         p.R = R; p.B = B;
         p.cap_nodes = (size_t)p.node_off[D + 1];
+        p.cap_slots = (size_t)p.slot_off[D + 1];
         p.cap_links = (size_t)p.link_off[D + 1] + 64;
         p.cap_rays = p.fanout ? (size_t)(R * widest_rcap) + 64 : 64;
         p.cap_pix = (size_t)(R * p.rcap[0]);                             // n_pix is indexed by the level-0 node
-        p.cap_shadow = p.cap_nodes * (size_t)std::max(L, 1);
+        p.cap_shadow = p.cap_slots * (size_t)std::max(L, 1);
         // 32-bit indexing inside the kernels: node and link indices, node * lights, and the shadow rays of one region of
         // one level (k_shadow numbers them inside such a segment)
         double widest_segment = 0;
-        for (int d = 0; d <= D; ++d) widest_segment = std::max(widest_segment, (double)p.rcap[d] * std::max(1, L) * (cfg->soft_shadows ? cfg->ss_samples : 1));
-        if (p.cap_nodes > 0x7fffffffull || p.cap_links > 0x7fffffffull || (double)p.cap_shadow > 2.0e9 || widest_segment > 2.0e9) {
+        for (int d = 0; d <= D; ++d) widest_segment = std::max(widest_segment, (double)p.rcap[d] * (double)p.slot_mul[d] * std::max(1, L) * (cfg->soft_shadows ? cfg->ss_samples : 1));
+        if (p.cap_nodes > 0x7fffffffull || p.cap_slots > 0x7fffffffull || p.cap_links > 0x7fffffffull || (double)p.cap_shadow > 2.0e9 || widest_segment > 2.0e9) {
             if (B <= 64) return c->fail(RT_ERR_CAPACITY, "batch too large for 32-bit indices");
             B /= 2; continue;
         }
@@ -1120,14 +1129,14 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         w.stats = (unsigned long long*)take(RT_S_TOTAL * sizeof(unsigned long long));
         for (int k = 0; k < 2; ++k) { w.q_a[k] = (float4*)take(cap_rays * 16); w.q_b[k] = (float4*)take(cap_rays * 16); }
         w.n_a = (float4*)take(cap_nodes * 16); w.n_b = (float4*)take(cap_nodes * 16); w.n_c = (float4*)take(cap_nodes * 16);
-        w.n_col = (float4*)take(cap_nodes * 16);
+        w.n_col = (float4*)take(plan.cap_slots * 16);
         if (f.textures) w.n_uv = (float2*)take(cap_nodes * 8);
         w.n_pix = (int*)take(cap_pix * 4);
         w.shadow = (float*)take(plan.cap_shadow * 4);
         w.link = (int*)take(cap_links * 4);
         if ((size_t)(q - arena) > RT_NOALLOC_BYTES) return c->fail(RT_ERR_CAPACITY, "rt_render_device_noalloc: work plan exceeds the scratch array");
     } else {
-        const bool grow = cap_nodes > c->n_a.n || cap_links > c->link.n || cap_rays > c->q_a[0].n || (size_t)n_slots > c->accum.n ||
+        const bool grow = cap_nodes > c->n_a.n || plan.cap_slots > c->n_col.n || cap_links > c->link.n || cap_rays > c->q_a[0].n || (size_t)n_slots > c->accum.n ||
                           (f.textures && cap_nodes > c->n_uv.n) || plan.cap_shadow > c->shadow.n || cap_pix > c->n_pix.n;
         if (grow) {
             // Recorded frames hold the addresses of the buffers that are about to be freed: drop every recording before any
@@ -1138,7 +1147,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         }
         for (int q = 0; q < 2; ++q) { RT_HIP(c, c->q_a[q].resize(cap_rays)); RT_HIP(c, c->q_b[q].resize(cap_rays)); }
         RT_HIP(c, c->n_a.resize(cap_nodes)); RT_HIP(c, c->n_b.resize(cap_nodes)); RT_HIP(c, c->n_c.resize(cap_nodes));
-        RT_HIP(c, c->n_col.resize(cap_nodes));
+        RT_HIP(c, c->n_col.resize(plan.cap_slots));
         if (f.textures) RT_HIP(c, c->n_uv.resize(cap_nodes));
         RT_HIP(c, c->n_pix.resize(cap_pix));
         RT_HIP(c, c->shadow.resize(plan.cap_shadow));
@@ -1155,6 +1164,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     for (int d = 0; d <= D + 2 && d < RT_MAX_LEVELS; ++d) {
         w.node_off[d] = (int)node_off[(size_t)std::min(d, D + 1)]; w.link_off[d] = (int)link_off[(size_t)d];
         w.node_rcap[d] = d <= D ? (int)rcap[(size_t)d] : 0; w.link_rcap[d] = (d >= 1 && d <= D) ? (int)rcap[(size_t)d] : 0;
+        w.slot_off[d] = (int)plan.slot_off[(size_t)std::min(d, D + 1)]; w.slot_mul[d] = (int)plan.slot_mul[(size_t)std::min(d, D + 1)];
     }
     w.regions = R;
 

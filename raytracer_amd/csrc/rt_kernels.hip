@@ -799,7 +799,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
         bool active = PRIMARY ? i < f.pix_count : i >= 0;
         Ray r; uint32_t path = 0, mult = 1; int slot = 0;
         bool replicated = false;            // an ancestor's reflection was already traced gr_samples times (soft shadows)
-        int copies = 1;                     // hits this ray records when it hits: it stands for a bundle of identical rays (f.bundle)
+        int copies = 1;                     // identical hits of the reference this ray's node stands for (f.bundle)
         r.o = mk(0, 0, 0); r.d = mk(0, 0, 1); r.time = 0.0f;
         if (active) {
             if (PRIMARY) active = generate_primary(f, i, r, path, slot);
@@ -843,9 +843,9 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
                     // reflection of a path is therefore traced gr_samples times for real (distinct path ids, so distinct
                     // sample sets); below it, where a contribution carries reflectivity^2 or less, identical rays are
                     // traced once again (the reference would trace gr_samples^depth of them).
-                    // f.bundle: the gr_samples rays are geometrically identical, so ONE queue entry is traced and its hit is
-                    // recorded gr_samples times (a bundle of consecutive hit records with their own path ids, hence their own
-                    // shadow samples); everything below a bundle stays a bundle of the same size, copy s under copy s.
+                    // f.bundle: the gr_samples rays are geometrically identical, so ONE queue entry is traced and its node
+                    // stands for gr_samples copies (with their own path ids, hence their own shadow samples, shadow counts
+                    // and colours); everything below a bundle stays a bundle of the same size, copy s under copy s.
                     n_reflect = (glossy || (f.replicate && !replicated)) ? f.gr_samples : 1;
                     n_entries = (f.bundle && !glossy) ? 1 : n_reflect;
                 }
@@ -881,13 +881,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) { int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
             const int total_children = __shfl(incl, 63, 64);
-            int total_hits = __popcll(hm), before = __popcll(hm & ((1ull << lane) - 1ull));
-            if (!PRIMARY && f.bundle) {                                   // hits of bundles take `copies` records each
-                int inc2 = hit ? copies : 0;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { int v = __shfl_up(inc2, off, 64); if (lane >= off) inc2 += v; }
-                total_hits = __shfl(inc2, 63, 64); before = inc2 - (hit ? copies : 0);
-            }
+            const int total_hits = __popcll(hm), before = __popcll(hm & ((1ull << lane) - 1ull));
             unsigned long long pair = 0;
             if (lane == 0 && (total_hits | total_children))
                 pair = atomicAdd((unsigned long long*)&w.ctr[RT_CTR_NODE(level, rg)],
@@ -896,7 +890,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
             if (hit) node = base_node + before;
             qslot = base_link + incl - n_children;
         }
-        if (hit && node + copies > node_cap) { w.stats[RT_S_ERR] = 1; hit = false; }
+        if (hit && node + 1 > node_cap) { w.stats[RT_S_ERR] = 1; hit = false; }
         node = hit ? node_base + rg * node_cap + node : -1;
         if (!PRIMARY && active) w.link[link_in + i] = node;
         if (hit) {
@@ -905,14 +899,13 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
             }
             qslot += rg * link_cap;                                      // the region's part of the next level's queue
             const int first_link = link_out + qslot;
-            // one record per copy of the bundle: same hit, own path id (own shadow samples), own place under the parent
-            for (int cp = 0; cp < copies; ++cp) {
-                const uint32_t cpath_self = cp ? mix32(path + 0x9E3779B1u * (uint32_t)cp) : path;
-                w.n_a[node + cp] = make_float4(h.p.x, h.p.y, h.p.z, r.time);
-                w.n_b[node + cp] = make_float4(h.n.x, h.n.y, h.n.z, i2f(h.gid));
-                if (f.textures) w.n_uv[node + cp] = make_float2(h.u, h.v);
-                const int packed = f.bundle ? (n_reflect | (cp << 13) | (1 << 29) | (refract ? (1 << 30) : 0)) : (n_reflect | (refract ? (1 << 30) : 0));
-                w.n_c[node + cp] = make_float4(i2f(n_children ? first_link : -1), weight, i2f((int)cpath_self), i2f(packed));
+            // one node for all `copies` of the hit: what differs per copy (shadow counts, colours) lives in the node's slots
+            {
+                w.n_a[node] = make_float4(h.p.x, h.p.y, h.p.z, r.time);
+                w.n_b[node] = make_float4(h.n.x, h.n.y, h.n.z, i2f(h.gid | (copies > 1 ? (int)0x80000000 : 0)));
+                if (f.textures) w.n_uv[node] = make_float2(h.u, h.v);
+                const int packed = f.bundle ? (n_reflect | (copies << 13) | (1 << 29) | (refract ? (1 << 30) : 0)) : (n_reflect | (refract ? (1 << 30) : 0));
+                w.n_c[node] = make_float4(i2f(n_children ? first_link : -1), weight, i2f((int)path), i2f(packed));
             }
             if (PRIMARY) w.n_pix[node] = slot;
             const float EPS = 1e-4f;
@@ -1036,12 +1029,14 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     int* s_stack = (int*)(s_mem + 2 * sc.n_nodes) + threadIdx.x;                      // [depth][thread], only with SUB
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
     // The launch's work = chunks of RT_BLOCK items inside segments; a segment = the hits of one region of one of the
-    // levels lv_begin..lv_end; an item = a (hit, light) pair or, for sample counts that do not tile a wavefront, a
-    // (hit, light, sample) ray.  Workgroup b takes chunks b, b + gridDim.x, ...
+    // levels lv_begin..lv_end; an item = a (slot, light) pair - slot = one copy of a hit, see DevWork - or, for sample
+    // counts that do not tile a wavefront, a (slot, light, sample) ray.  Workgroup b takes chunks b, b + gridDim.x, ...
     constexpr int MAX_SEG = RT_MAX_LEVELS * RT_REGIONS;
     __shared__ int s_pre[MAX_SEG + 1];                                  // first chunk of every segment
     __shared__ unsigned s_items[MAX_SEG];                               // shadow rays of the segment
     __shared__ int s_nbase[MAX_SEG];                                    // node index of the segment's first hit
+    __shared__ int s_sbase[MAX_SEG];                                    // slot of that node's copy 0
+    __shared__ int s_mul[MAX_SEG];                                      // slots per node in the segment
     const int L = sc.n_lights;
     constexpr bool FAST = MODE == 2;
     const int SS = MODE ? f.ss_samples : 1;
@@ -1052,8 +1047,10 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     const int n_seg = (lv_end - lv_begin + 1) * w.regions;
     for (int sg = threadIdx.x; sg < n_seg; sg += blockDim.x) {
         const int lv = lv_begin + sg / w.regions, rg = sg % w.regions;
-        s_items[sg] = (unsigned)min(w.ctr[RT_CTR_NODE(lv, rg)], w.node_rcap[lv]) * per;
+        s_items[sg] = (unsigned)min(w.ctr[RT_CTR_NODE(lv, rg)], w.node_rcap[lv]) * (unsigned)w.slot_mul[lv] * per;
         s_nbase[sg] = w.node_off[lv] + rg * w.node_rcap[lv];
+        s_sbase[sg] = w.slot_off[lv] + rg * w.node_rcap[lv] * w.slot_mul[lv];
+        s_mul[sg] = w.slot_mul[lv];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1075,7 +1072,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     const float4 light0 = sc.lights[0];                                 // count > 0 implies a light; the usual scene has one
 
     // One sample ray: hard shadows (raytracer.cpp:509-530) or sample j of a soft shadow (raytracer.cpp:534-571).
-    auto sample_unblocked = [&](int node, int l, int j, const float4 a, const float4 lt) __attribute__((always_inline)) -> bool {
+    auto sample_unblocked = [&](int node, int cp, int l, int j, const float4 a, const float4 lt) __attribute__((always_inline)) -> bool {
         const V3 p = mk(a.x, a.y, a.z);
         Ray sr; sr.time = a.w;
         Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
@@ -1085,7 +1082,8 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
             sr.o = p + mk(b.x, b.y, b.z) * 1e-2f;                        // raytracer.cpp:515: unflipped geometric normal
             return !trace<true, SUB>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
         }
-        const uint32_t path = (uint32_t)f2i(w.n_c[node].z);
+        uint32_t path = (uint32_t)f2i(w.n_c[node].z);
+        if (cp) path = mix32(path + 0x9E3779B1u * (uint32_t)cp);        // every copy of a hit draws its own samples
         const uint3 q = pcg3d(path ^ (f.seed * 0x9E3779B1u), (uint32_t)j, (uint32_t)l * 16u + STREAM_SHADOW);
         const V3 jit = unit_sphere(u01(q.x), u01(q.y), u01(q.z)) * f.light_radius;
         const V3 h2l = mk(lt.x + jit.x, lt.y + jit.y, lt.z + jit.z) - p;
@@ -1117,7 +1115,8 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         // pairs are expanded to rays, RT_BLOCK at a time, SS neighbouring lanes per pair, and counted with a ballot.
         // The per-pair work is so done once, not once per sample, and every wavefront that traces is full of rays that
         // need tracing (the workgroup's last one aside).
-        __shared__ int s_q[2 * RT_BLOCK];
+        __shared__ int s_q[2 * RT_BLOCK], s_qnode[2 * RT_BLOCK];      // queued pairs: index into `out`; node
+        __shared__ unsigned short s_qcp[2 * RT_BLOCK];                // ... and which of the node's copies (< 4096)
         __shared__ int s_qn;
         if (threadIdx.x == 0) s_qn = 0;
         __syncthreads();
@@ -1125,25 +1124,35 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
             while (seg < n_seg - 1 && g >= __builtin_amdgcn_readfirstlane(s_pre[seg + 1])) ++seg;
             const unsigned i = (unsigned)(g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * RT_BLOCK + threadIdx.x;   // pair of the segment
-            bool queue = false; int item = 0;
+            bool queue = false; int item = 0, qnode = 0, qcp = 0;
             if (i < (unsigned)__builtin_amdgcn_readfirstlane((int)s_items[seg])) {
                 int dense, l;
                 if (L == 1) { dense = (int)i; l = 0; } else { dense = (int)(i / (unsigned)L); l = (int)(i % (unsigned)L); }
-                const int node = __builtin_amdgcn_readfirstlane(s_nbase[seg]) + dense;
-                item = node * L + l;
+                const int mul = __builtin_amdgcn_readfirstlane(s_mul[seg]);
+                int node_local = dense, cp = 0;
+                if (mul > 1) {
+                    if ((mul & (mul - 1)) == 0) { node_local = dense >> (31 - __clz(mul)); cp = dense & (mul - 1); }
+                    else { node_local = dense / mul; cp = dense - node_local * mul; }
+                }
+                const int node = __builtin_amdgcn_readfirstlane(s_nbase[seg]) + node_local;
+                item = (__builtin_amdgcn_readfirstlane(s_sbase[seg]) + dense) * L + l;
+                qnode = node; qcp = cp;
                 const float4 a = w.n_a[node], b = w.n_b[node];
-                const float4 lt = (L == 1) ? light0 : sc.lights[l];
-                if (!faces_light(a, b, lt)) out[item] = 0;
-                else if (!SUB && MODE != 0 && cull &&
-                         !cone_may_hit(sc, f.motion_blur != 0, mk(a.x, a.y, a.z), mk(lt.x, lt.y, lt.z), f.light_radius)) out[item] = SS;
-                else queue = true;
+                // a node of a level with several slots per node has either one copy or all of them (top bit of the id word)
+                if (cp == 0 || f2i(b.w) < 0) {
+                    const float4 lt = (L == 1) ? light0 : sc.lights[l];
+                    if (!faces_light(a, b, lt)) out[item] = 0;
+                    else if (!SUB && MODE != 0 && cull &&
+                             !cone_may_hit(sc, f.motion_blur != 0, mk(a.x, a.y, a.z), mk(lt.x, lt.y, lt.z), f.light_radius)) out[item] = SS;
+                    else queue = true;
+                }
             }
             {
                 const unsigned long long m = __ballot(queue);
                 int base = 0;
                 if (__lane_id() == 0 && m) base = atomicAdd(&s_qn, __popcll(m));
                 base = __shfl(base, 0, 64);
-                if (queue) s_q[base + __popcll(m & ((1ull << __lane_id()) - 1ull))] = item;
+                if (queue) { const int at = base + __popcll(m & ((1ull << __lane_id()) - 1ull)); s_q[at] = item; s_qnode[at] = qnode; s_qcp[at] = (unsigned short)qcp; }
             }
             __syncthreads();
             int qn = s_qn;
@@ -1156,10 +1165,10 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                 bool unblocked = false; int it = 0;
                 if (active) {
                     it = s_q[first + k];
-                    int node, l;
-                    if (L == 1) { node = it; l = 0; } else { node = it / L; l = it % L; }
+                    const int node = s_qnode[first + k], cp = (int)s_qcp[first + k];
+                    const int l = (L == 1) ? 0 : it % L;
                     ++n_rays;
-                    unblocked = sample_unblocked(node, l, j, w.n_a[node], (L == 1) ? light0 : sc.lights[l]);
+                    unblocked = sample_unblocked(node, cp, l, j, w.n_a[node], (L == 1) ? light0 : sc.lights[l]);
                 }
                 const unsigned long long m = __ballot(active && unblocked);
                 if (active && j == 0) {
@@ -1184,12 +1193,16 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         const unsigned grp = i / (unsigned)SS; const int j = (int)(i % (unsigned)SS);
         int dense, l;
         if (L == 1) { dense = (int)grp; l = 0; } else { dense = (int)(grp / (unsigned)L); l = (int)(grp % (unsigned)L); }
-        const int node = __builtin_amdgcn_readfirstlane(s_nbase[seg]) + dense;
+        const int mul = __builtin_amdgcn_readfirstlane(s_mul[seg]);
+        int node_local = dense, cp = 0;
+        if (mul > 1) { node_local = dense / mul; cp = dense - node_local * mul; }
+        const int node = __builtin_amdgcn_readfirstlane(s_nbase[seg]) + node_local;
         const float4 a = w.n_a[node], b = w.n_b[node];
+        if (cp != 0 && f2i(b.w) >= 0) continue;                          // a node with one copy in a level of bundles
         const float4 lt = (L == 1) ? light0 : sc.lights[l];
         if (!faces_light(a, b, lt)) continue;                            // the host zeroed the counts for this layout
         ++n_rays;
-        if (sample_unblocked(node, l, j, a, lt)) atomicAdd(&out[node * L + l], 1);
+        if (sample_unblocked(node, cp, l, j, a, lt)) atomicAdd(&out[(__builtin_amdgcn_readfirstlane(s_sbase[seg]) + dense) * L + l], 1);
     }
     if (f.count_stats) block_stat_add(&w.stats[RT_S_SHADOW], n_rays, s_tmp);
 }
@@ -1239,6 +1252,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, Dev
     const int L = sc.n_lights;
     const int* __restrict__ sh = (const int*)w.shadow;
     const V3 cam = mk(f.cam_loc[0], f.cam_loc[1], f.cam_loc[2]);
+    const int mul = w.slot_mul[level], mul_child = w.slot_mul[level + 1];
+    const float inv_gr = 1.0f / (float)f.gr_samples;                     // raytracer.cpp:436-439
     unsigned long long n_shaded = 0;
     int seg = 0;
     for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
@@ -1246,9 +1261,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, Dev
         const int k = (g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * RT_BLOCK + (int)threadIdx.x;
         if (k >= __builtin_amdgcn_readfirstlane(s_cnt[seg])) continue;
         const int node = w.node_off[level] + seg * w.node_rcap[level] + k;
-        ++n_shaded;
+        const int slot0 = w.slot_off[level] + (node - w.node_off[level]) * mul;      // slot of the node's copy 0
         float4 a = w.n_a[node], b = w.n_b[node], c = w.n_c[node];
-        const int gid = f2i(b.w);
+        const int gid = f2i(b.w) & 0x7fffffff;
         float4 m0 = sc.mats[3 * gid], m1 = sc.mats[3 * gid + 1], m2 = sc.mats[3 * gid + 2];
         V3 p = mk(a.x, a.y, a.z), N = mk(b.x, b.y, b.z);
         const float ka = 0.25f, shiny = m0.w;
@@ -1266,82 +1281,114 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, Dev
             float4 tx = sc.texels[td.z + yi * td.x + xi];
             mat = mk(tx.x, tx.y, tx.z);
         }
-        V3 V = normalise(cam - p);
-        V3 col = mk(ka * mat.x, ka * mat.y, ka * mat.z);
-        for (int l = 0; l < L; ++l) {
-            float4 lt = sc.lights[l];
-            V3 Lv = mk(lt.x - p.x, lt.y - p.y, lt.z - p.z);
-            float L_len = len_ref(Lv);
-            Lv = normalise(Lv);
-            float irr = (float)((double)lt.w / ((double)1.0f + (double)L_len * (double)L_len));   // raytracer.cpp:320
-            V3 H = normalise(Lv + V);
-            float N_L = smax(0.0f, dot(N, Lv));
-            float N_H = smax(0.0f, dot(N, H));
-            int cnt = sh[node * L + l];
-            float shadow = f.soft_shadows ? (float)cnt / (float)f.ss_samples : (cnt ? 1.0f : 0.0f);
-            float pw = powf_ref(N_H, shiny);
-            col.x += shadow * mat.x * N_L * irr + 0.5f * m1.x * pw * irr;
-            col.y += shadow * mat.y * N_L * irr + 0.5f * m1.y * pw * irr;
-            col.z += shadow * mat.z * N_L * irr + 0.5f * m1.z * pw * irr;
+        // what the node's children contribute (raytracer.cpp:369-503): the same structure for every copy
+        const int first = f2i(c.x), packed = f2i(c.w);
+        const bool has_children = level < f.max_depth;
+        const bool bundle = (packed >> 29) & 1;
+        const int n_reflect = bundle ? (packed & 0x1fff) : (packed & 0x1fffffff);
+        const int copies = bundle ? ((packed >> 13) & 0xffff) : 1;
+        const bool refract = (packed >> 30) & 1;
+        const float reflectivity = m2.z;
+        n_shaded += (unsigned)copies;
+        // slot of copy 0 of a child node (children live one level down)
+        auto child_slot = [&](int ch) { return w.slot_off[level + 1] + (ch - w.node_off[level + 1]) * mul_child; };
+        int refl_slot = -1, refr_slot = -1;                              // bundles and single reflections: one child node
+        if (has_children) {
+            if ((n_reflect == 1 || bundle) && n_reflect > 0) { const int ch = w.link[first]; if (ch >= 0) refl_slot = child_slot(ch); }
+            if (refract) { const int ch = w.link[first + (bundle ? (n_reflect ? 1 : 0) : n_reflect)]; if (ch >= 0) refr_slot = child_slot(ch); }
         }
-        col.x = smin(1.0f, smax(col.x, 0.0f));                           // raytracer.cpp:342-344
-        col.y = smin(1.0f, smax(col.y, 0.0f));
-        col.z = smin(1.0f, smax(col.z, 0.0f));
 
-        if (level < f.max_depth) {                                       // raytracer.cpp:369-503
-            const int first = f2i(c.x), packed = f2i(c.w);
-            // bundle: this hit is copy `cp` of a bundle of identical hits; a child ray was traced once and recorded as a
-            // bundle of consecutive hits (link = its first one), copy cp of the child under copy cp of the parent
-            const bool bundle = (packed >> 29) & 1;
-            const int n_reflect = bundle ? (packed & 0x1fff) : (packed & 0x1fffffff);
-            const int cp = bundle ? ((packed >> 13) & 0xffff) : 0;
-            const bool refract = (packed >> 30) & 1;
-            const float reflectivity = m2.z;
-            V3 rc = mk(0.0f, 0.0f, 0.0f);
-            if (n_reflect == 1) {
-                int ch = w.link[first];
-                if (bundle && ch >= 0) ch += cp;
-                V3 cc = mk(0.0f, 0.0f, 0.0f);
-                if (ch >= 0) { float4 q = w.n_col[ch]; cc = mk(q.x, q.y, q.z); }
-                for (int s = 0; s < f.gr_samples; ++s) rc = rc + cc;     // the gr_samples identical rays of raytracer.cpp:400-432
-            } else if (bundle) {
-                const int base = n_reflect ? w.link[first] : -1;         // n_reflect consecutive hits of one traced ray
-                for (int s = 0; s < n_reflect; ++s) {
-                    if (base >= 0) { float4 q = w.n_col[base + cp * n_reflect + s]; rc = rc + mk(q.x, q.y, q.z); }
-                    else rc = rc + mk(0.0f, 0.0f, 0.0f);
-                }
-            } else {
-                for (int s = 0; s < n_reflect; ++s) {
-                    int ch = w.link[first + s];
-                    if (ch >= 0) { float4 q = w.n_col[ch]; rc = rc + mk(q.x, q.y, q.z); }
-                    else rc = rc + mk(0.0f, 0.0f, 0.0f);
-                }
+        const V3 V = normalise(cam - p);
+        // The shading of a hit (raytracer.cpp:262-347) depends on the copy only through the shadow factor: per light the
+        // two terms are formed once, the copies' colours are built up in their slots (one pass for the usual one light).
+        for (int l = 0; l < (L > 0 ? L : 1); ++l) {
+            V3 diff = mk(0.0f, 0.0f, 0.0f), spec = mk(0.0f, 0.0f, 0.0f); float N_L = 0.0f, irr = 0.0f;
+            if (L > 0) {
+                float4 lt = sc.lights[l];
+                V3 Lv = mk(lt.x - p.x, lt.y - p.y, lt.z - p.z);
+                float L_len = len_ref(Lv);
+                Lv = normalise(Lv);
+                irr = (float)((double)lt.w / ((double)1.0f + (double)L_len * (double)L_len));   // raytracer.cpp:320
+                V3 H = normalise(Lv + V);
+                N_L = smax(0.0f, dot(N, Lv));
+                float N_H = smax(0.0f, dot(N, H));
+                float pw = powf_ref(N_H, shiny);
+                diff = mat; spec = mk(0.5f * m1.x * pw * irr, 0.5f * m1.y * pw * irr, 0.5f * m1.z * pw * irr);
             }
-            const float inv = 1.0f / (float)f.gr_samples;                // raytracer.cpp:436-439
-            rc = rc * inv;
-            rc = rc * reflectivity;
-            col = col + rc;
-            if (refract) {                                               // raytracer.cpp:494-497
-                int ch = w.link[first + (bundle ? (n_reflect ? 1 : 0) : n_reflect)];
-                if (bundle && ch >= 0) ch += cp;
-                V3 fc = mk(0.0f, 0.0f, 0.0f);
-                if (ch >= 0) { float4 q = w.n_col[ch]; fc = mk(q.x, q.y, q.z); }
-                col = col + fc * c.y;
-            }
-            col.x = smin(1.0f, smax(0.0f, col.x));                       // raytracer.cpp:501-503
-            col.y = smin(1.0f, smax(0.0f, col.y));
-            col.z = smin(1.0f, smax(0.0f, col.z));
-        }
-        w.n_col[node] = make_float4(col.x, col.y, col.z, 0.0f);
-        if (level == 0) {
-            const int slot = w.n_pix[node];
-            if (f.direct_out) {
-                // one sample per pixel in one batch: the sum is this colour and the average divides by one, so the
-                // pixel can be written now (the frame start zeroed the image instead of the sums)
-                store_pixel(f, f.direct_out, f.direct_tile_major, slot, col.x * 1.0f, col.y * 1.0f, col.z * 1.0f);
-            } else {
-                float4 acc = w.accum[slot];
-                w.accum[slot] = make_float4(acc.x + col.x, acc.y + col.y, acc.z + col.z, 0.0f);
+            const bool first_light = l == 0, last_light = l >= L - 1;
+            // copies four at a time: everything a group reads is loaded before anything is stored, so the loads of a
+            // group are in flight together (a lane with 16 copies otherwise waits for sixteen round trips in a row)
+            for (int cp0 = 0; cp0 < copies; cp0 += 4) {
+                int cnt4[4]; float4 own4[4], refl4[4], refr4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cp = cp0 + u, slot = slot0 + cp;
+                    const bool on = cp < copies;
+                    cnt4[u] = (on && L > 0) ? sh[slot * L + l] : 0;
+                    own4[u] = (on && !first_light) ? w.n_col[slot] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    refl4[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); refr4[u] = refl4[u];
+                    if (on && last_light && has_children) {
+                        if (n_reflect == 1 && refl_slot >= 0) refl4[u] = w.n_col[refl_slot + cp];
+                        if (refr_slot >= 0) refr4[u] = w.n_col[refr_slot + cp];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cp = cp0 + u, slot = slot0 + cp;
+                    if (cp >= copies) break;
+                    V3 col = first_light ? mk(ka * mat.x, ka * mat.y, ka * mat.z) : mk(own4[u].x, own4[u].y, own4[u].z);
+                    if (L > 0) {
+                        const int cnt = cnt4[u];
+                        const float shadow = f.soft_shadows ? (float)cnt / (float)f.ss_samples : (cnt ? 1.0f : 0.0f);
+                        col.x += shadow * diff.x * N_L * irr + spec.x;
+                        col.y += shadow * diff.y * N_L * irr + spec.y;
+                        col.z += shadow * diff.z * N_L * irr + spec.z;
+                    }
+                    if (last_light) {
+                        col.x = smin(1.0f, smax(col.x, 0.0f));           // raytracer.cpp:342-344
+                        col.y = smin(1.0f, smax(col.y, 0.0f));
+                        col.z = smin(1.0f, smax(col.z, 0.0f));
+                        if (has_children) {
+                            V3 rc = mk(0.0f, 0.0f, 0.0f);
+                            if (n_reflect == 1) {
+                                // copy cp of the child under copy cp of the parent
+                                const V3 cc = mk(refl4[u].x, refl4[u].y, refl4[u].z);
+                                for (int s2 = 0; s2 < f.gr_samples; ++s2) rc = rc + cc;     // the gr_samples identical rays of raytracer.cpp:400-432
+                            } else if (bundle) {
+                                // one traced ray whose node holds this hit's n_reflect children as its copies
+                                for (int s2 = 0; s2 < n_reflect; ++s2) {
+                                    if (refl_slot >= 0) { const float4 q = w.n_col[refl_slot + cp * n_reflect + s2]; rc = rc + mk(q.x, q.y, q.z); }
+                                    else rc = rc + mk(0.0f, 0.0f, 0.0f);
+                                }
+                            } else {
+                                for (int s2 = 0; s2 < n_reflect; ++s2) {
+                                    const int ch = w.link[first + s2];
+                                    if (ch >= 0) { const float4 q = w.n_col[child_slot(ch)]; rc = rc + mk(q.x, q.y, q.z); }
+                                    else rc = rc + mk(0.0f, 0.0f, 0.0f);
+                                }
+                            }
+                            rc = rc * inv_gr;
+                            rc = rc * reflectivity;
+                            col = col + rc;
+                            if (refract) col = col + mk(refr4[u].x, refr4[u].y, refr4[u].z) * c.y;     // raytracer.cpp:494-497
+                            col.x = smin(1.0f, smax(0.0f, col.x));       // raytracer.cpp:501-503
+                            col.y = smin(1.0f, smax(0.0f, col.y));
+                            col.z = smin(1.0f, smax(0.0f, col.z));
+                        }
+                        if (level == 0) {
+                            const int pslot = w.n_pix[node];
+                            if (f.direct_out) {
+                                // one sample per pixel in one batch: the sum is this colour and the average divides by one, so the
+                                // pixel can be written now (the frame start zeroed the image instead of the sums)
+                                store_pixel(f, f.direct_out, f.direct_tile_major, pslot, col.x * 1.0f, col.y * 1.0f, col.z * 1.0f);
+                            } else {
+                                float4 acc = w.accum[pslot];
+                                w.accum[pslot] = make_float4(acc.x + col.x, acc.y + col.y, acc.z + col.z, 0.0f);
+                            }
+                        }
+                    }
+                    if (!(last_light && level == 0)) w.n_col[slot] = make_float4(col.x, col.y, col.z, 0.0f);
+                }
             }
         }
     }

@@ -94,7 +94,7 @@ struct DevFrame {
     int skip_unlit;                // shadow rays of (hit, light) pairs whose N.L is clearly negative are not traced
     int replicate;                 // soft shadows: the first reflection of a path is traced gr_samples times (see k_extend)
     int cull_cones;                // soft shadows of tiny scenes: (hit, light) pairs whose whole cone of sample rays misses everything are not traced
-    int bundle;                    // ... as ONE traced ray whose hit is recorded gr_samples times (replicate, no glossy perturbation)
+    int bundle;                    // ... as ONE traced ray whose node has gr_samples copies (replicate, no glossy perturbation)
     int count_stats;               // kernels add their ray counts to DevWork::stats (one atomic per workgroup and counter)
     // sharding
     int tiles_x, tiles_y, n_local_tiles;
@@ -107,12 +107,18 @@ struct DevFrame {
 };
 
 // ---- work buffers ---------------------------------------------------------------------------------------
-// Hit-tree node (one per shaded hit), structure of arrays:
-//   n_a = (hit point xyz, hit time)           n_b = (geometric normal xyz, bits gid)
-//   n_c = (bits first_link | -1, refraction weight, bits path id, bits n_reflection_children | has_refraction << 30), or, for a hit
-//         that is copy cp of a bundle: bits n_reflection_children (13) | cp << 13 | 1 << 29 | has_refraction << 30
-//   n_uv = (u, v) when texture mapping is on   n_col = resolved colour (r, g, b, 0)
+// Hit-tree node (one per traced ray that hit), structure of arrays:
+//   n_a = (hit point xyz, hit time)           n_b = (geometric normal xyz, bits gid | 1 << 31 when the node has more than one copy)
+//   n_c = (bits first_link | -1, refraction weight, bits path id, bits n_reflection_children | has_refraction << 30), or, in
+//         frames with bundles (DevFrame::bundle): bits n_reflection_children (13) | copies << 13 | 1 << 29 | has_refraction << 30
+//   n_uv = (u, v) when texture mapping is on
 //   n_pix (level 0 only) = local pixel slot.
+// A node stands for `copies` identical hits of the reference (a bundle: its gr_samples identical reflection rays, and
+// everything below them) that differ only in the shadow samples they draw.  What differs per copy lives in SLOTS:
+//   n_col[slot] = resolved colour (r, g, b, 0)     shadow[slot * lights + light] = unblocked samples
+//   slot of copy cp of a node of `level` = slot_off[level] + (node - node_off[level]) * slot_mul[level] + cp
+// with slot_mul = 1 everywhere without bundles (slot == node), and gr_samples for the levels >= 1 of a frame with bundles
+// (a node there has 1 or gr_samples copies; copy cp's path id is the node's for cp = 0, else mix32(id + 0x9E3779B1 * cp)).
 // Every level's part of the node arena and of the ray queue is cut into `regions` (<= RT_REGIONS) regions of equal capacity, each
 // filled from its start through its own counter (see ctr below):
 //   node index = node_off[level] + region * node_rcap[level] + order of allocation inside the region
@@ -132,6 +138,8 @@ struct DevWork {
     unsigned cap_nodes;            // total node capacity = node_off[max_depth + 1]
     int node_off[RT_MAX_LEVELS];   // [level] first node of the level's region; [max_depth + 1] = end
     int link_off[RT_MAX_LEVELS];   // [level] first link of the rays traced at `level` (level >= 1); [max_depth + 1] = end
+    int slot_off[RT_MAX_LEVELS];   // [level] first slot of the level's nodes, see above
+    int slot_mul[RT_MAX_LEVELS];   // [level] slots per node of the level
     int node_rcap[RT_MAX_LEVELS];  // [level] nodes one region of the level can hold
     int link_rcap[RT_MAX_LEVELS];  // [level] rays one region of the level's queue can hold (level >= 1)
     int regions;                   // regions in use: 1, 2, 4 or RT_REGIONS (small batches do not need the spread)
