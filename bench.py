@@ -276,12 +276,21 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     if world > 1:
         P = min(P, 3)                                 # the communicator's stream takes the fourth hardware queue
 
-    def new_renderer():
-        rr = api.Renderer(local, workspace_bytes=16 << 30)
-        if P >= 3 or world > 1:
-            rr.set_option("overlap", 0)
+    def set_mode(rr, in_flight: bool):
+        """The library's defaults serve one frame at a time (shadow rays of the primary hits on a forked stream, one
+        workgroup per chunk or two in the soft-shadow launches so that no workgroup holds the frame up).  Frames in
+        flight fill each other's gaps instead: no forked streams (hardware queues are few) and the smaller grid, which
+        costs fewer workgroup start-ups."""
+        rr.set_option("overlap", 0 if (in_flight and (P >= 3 or world > 1)) else 1)
+        rr.set_option("grid_shadow", 1536 if (in_flight and P >= 3 and soft_small) else 0)
         for kv in filter(None, os.environ.get("RT_BENCH_OPTS", "").split(",")):      # development: name=value library options
             rr.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+
+    soft_small = bool(cfg.soft_shadows) and wl["scene"] != "random"
+
+    def new_renderer():
+        rr = api.Renderer(local, workspace_bytes=16 << 30)
+        set_mode(rr, True)
         return rr
 
     r = new_renderer()
@@ -343,6 +352,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
             print(f"[bench {name}] {msg}", file=sys.stderr, flush=True)
 
     note(f"scene uploaded in {upload_s:.2f} s")
+    set_mode(r, False)       # ray counts, stage times and the latency of one frame: the library as a one-frame-at-a-time caller gets it
     st = r.render_device(cfg, block.data_ptr(), want_stats=True)     # ray counts (the counting kernel variants)
     heavy = st.ms_total > 150.0                                      # a frame of hundreds of ms: no extra frames beyond the timed ones
     note(f"first frame {st.ms_total:.1f} ms, {st.total_rays()} rays, {st.batches} batches")
@@ -391,8 +401,9 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
 
     # latency of one frame alone (enqueue -> done), next to the throughput the timed loop measures
     torch.cuda.synchronize(dev)
-    n_lat = 1 if heavy else (10 if spp < 16 else 2)
-    r.render_device(cfg, block.data_ptr()); r.synchronize()
+    n_lat = 1 if heavy else (20 if spp < 16 else 2)
+    for _ in range(1 if heavy else 3):                   # (the third request replays the frame's recorded graph)
+        r.render_device(cfg, block.data_ptr()); r.synchronize()
     t_lat = time.perf_counter()
     for _ in range(n_lat):
         r.render_device(cfg, block.data_ptr()); r.synchronize()
@@ -413,6 +424,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     # between two blocks, so it needs four frames before both graphs exist
     # Part of the set-up, not of the warm-up: these frames make every context record its graph(s).  Then exactly `warmup`
     # untimed steps and `steps` timed ones.
+    set_mode(r, True)
     prime_steps = 0 if heavy else (4 if pipelined else 2) * P
     note(f"one frame alone {frame_latency_ms:.2f} ms; {prime_steps} frames to record the frame graphs, warming up ({warmup}) and timing {steps} steps")
     for _ in range(prime_steps):

@@ -32,6 +32,15 @@ hipError_t rt_build_scene_bounds(hipStream_t s, const DevPrimSet& set, float out
 hipError_t rt_build_hierarchies(hipStream_t s, const DevPrimSet& set, const BuildGroup* groups, int n_groups, long long n_items,
                                 double sphere_e, bool motion, float4* nodes, int* entries, float final6[6]);
 
+// Records in hierarchy order.  `entries` / `order` = the slot arrays (absolute slots, a group's start at 4 * node_base):
+// on return entries[slot] names the primitive's new place, class << 30 | index into out_planes / out_cubes / out_spheres
+// (inside the group's own class ranges, so records outside the groups keep their indices: copy them beforehand), and
+// order[slot] holds the entry as it was, i.e. the primitive's place in the reference's testing order, which decides
+// exact ties.  The out arrays must not alias the set's.  Every slot of the groups must be written (-1 = unused).
+// Synchronises the stream.
+hipError_t rt_build_reorder(hipStream_t s, const DevPrimSet& set, const BuildGroup* groups, int n_groups, int* entries, int* order,
+                            float4* out_planes, float4* out_cubes, float4* out_spheres);
+
 // Leaf-order copies of the file-order primitive records.  leaf_desc (host): per leaf (first id in prim_ids, planes,
 // cubes, spheres) and (first leaf-order plane, cube, sphere, 0).  prim_ids_dev holds validated indices.
 struct LeafGather { int first_id, n_planes, n_cubes, n_spheres, lp0, lc0, ls0, pad; };

@@ -19,6 +19,7 @@
 #include "rt_build.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <cmath>
 #include <cstring>
@@ -388,6 +389,60 @@ __global__ __launch_bounds__(256) void k_gather_leaves(DevPrimSet F, const int* 
     }
 }
 
+
+// ---- records in hierarchy order ------------------------------------------------------------------------
+// A run's primitives are tested together, so their records should sit together.  Slots are numbered in hierarchy order
+// (run after run), and the k-th plane / cube / sphere met in that order inside a group moves to the k-th place of the
+// group's range of its class: the records of a run become neighbours in memory.  What the old index stood for - the
+// reference's testing order, which decides exact ties - is kept per slot in `order`.
+struct ClassCount { unsigned p, c, v, pad; };                // planes, cubes and used slots before a slot
+struct ClassPlus {
+    __host__ __device__ ClassCount operator()(const ClassCount& a, const ClassCount& b) const {
+        ClassCount r; r.p = a.p + b.p; r.c = a.c + b.c; r.v = a.v + b.v; r.pad = 0u; return r;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_slot_flags(const int* __restrict__ entries, long long slot0, long long n_slots, ClassCount* __restrict__ flags) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (long long)gridDim.x * blockDim.x) {
+        const int e = entries[slot0 + i];
+        ClassCount f; f.pad = 0u;
+        const unsigned cls = (unsigned)e >> 30;
+        f.p = cls == 0u ? 1u : 0u; f.c = cls == 1u ? 1u : 0u; f.v = e != -1 ? 1u : 0u;          // -1 (class bits 3) = unused slot
+        flags[i] = f;
+    }
+}
+
+// blockIdx.y = group.  entries: old index in, new index out; order: the old entry (or -1) of every slot.
+__global__ __launch_bounds__(256) void k_reorder(DevPrimSet S, const BuildGroup* __restrict__ groups, long long slot0, const ClassCount* __restrict__ scan,
+                                                 int* __restrict__ entries, int* __restrict__ order,
+                                                 float4* __restrict__ op, float4* __restrict__ oc, float4* __restrict__ os) {
+    const BuildGroup g = groups[blockIdx.y];
+    const long long first = 4ll * g.node_base, n = 4ll << g.depth;
+    const ClassCount base = scan[first - slot0];
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+        const long long slot = first + k;
+        const int e = entries[slot];
+        order[slot] = e;
+        if (e == -1) continue;
+        const ClassCount cc = scan[slot - slot0];
+        const unsigned cls = (unsigned)e >> 30; const size_t old = (size_t)((unsigned)e & 0x3fffffffu);
+        const unsigned rp = cc.p - base.p, rc = cc.c - base.c, rs = (cc.v - base.v) - rp - rc;
+        if (cls == 0u) {
+            const size_t to = (size_t)g.p0 + rp;
+            for (int w = 0; w < 3; ++w) op[3 * to + w] = S.planes[3 * old + w];
+            entries[slot] = (int)to;
+        } else if (cls == 1u) {
+            const size_t to = (size_t)g.c0 + rc;
+            for (int w = 0; w < 6; ++w) oc[6 * to + w] = S.cubes[6 * old + w];
+            entries[slot] = (int)((1u << 30) | (unsigned)to);
+        } else {
+            const size_t to = (size_t)g.s0 + rs;
+            os[2 * to] = S.spheres[2 * old]; os[2 * to + 1] = S.spheres[2 * old + 1];
+            entries[slot] = (int)((2u << 30) | (unsigned)to);
+        }
+    }
+}
+
 struct Scratch {                       // device allocations of one build, freed on every path out
     std::vector<void*> ptrs;
     ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
@@ -501,6 +556,33 @@ hipError_t rt_build_gather_leaves(hipStream_t s, const DevPrimSet& fileset, cons
     long long max_n = 0;
     for (int i = 0; i < n_leaves; ++i) { long long n = (long long)leaves[i].n_planes + leaves[i].n_cubes + leaves[i].n_spheres; max_n = n > max_n ? n : max_n; }
     hipLaunchKernelGGL(k_gather_leaves, dim3(grid_for(max_n), n_leaves), dim3(256), 0, s, fileset, prim_ids_dev, d_leaves, leaf_planes, leaf_cubes, leaf_spheres);
+    BUILD_TRY(hipGetLastError());
+    return hipStreamSynchronize(s);
+}
+
+hipError_t rt_build_reorder(hipStream_t s, const DevPrimSet& set, const BuildGroup* groups, int n_groups, int* entries, int* order,
+                            float4* out_planes, float4* out_cubes, float4* out_spheres) {
+    if (n_groups <= 0) return hipSuccess;
+    if (n_groups > 65535) return hipErrorInvalidValue;
+    long long slot0 = 0x7fffffffffffffffll, slot1 = 0; int max_depth = 1;
+    for (int g = 0; g < n_groups; ++g) {
+        const long long a = 4ll * groups[g].node_base, b = a + (4ll << groups[g].depth);
+        slot0 = a < slot0 ? a : slot0; slot1 = b > slot1 ? b : slot1; max_depth = groups[g].depth > max_depth ? groups[g].depth : max_depth;
+    }
+    const long long n_slots = slot1 - slot0;
+    Scratch sc; BuildGroup* d_groups; ClassCount *d_flags, *d_scan;
+    BUILD_TRY(sc.get(&d_groups, (size_t)n_groups)); BUILD_TRY(sc.get(&d_flags, (size_t)n_slots)); BUILD_TRY(sc.get(&d_scan, (size_t)n_slots));
+    BUILD_TRY(hipMemcpyAsync(d_groups, groups, sizeof(BuildGroup) * (size_t)n_groups, hipMemcpyHostToDevice, s));
+    // slots between groups (none today) would hold stale values: count what the entries say, group by group they are all written
+    hipLaunchKernelGGL(k_slot_flags, dim3(grid_for(n_slots)), dim3(256), 0, s, entries, slot0, n_slots, d_flags);
+    BUILD_TRY(hipGetLastError());
+    size_t temp_bytes = 0;
+    ClassCount zero{}; zero.p = zero.c = zero.v = zero.pad = 0u;
+    BUILD_TRY(rocprim::exclusive_scan(nullptr, temp_bytes, d_flags, d_scan, zero, (size_t)n_slots, ClassPlus(), s));
+    char* d_temp; BUILD_TRY(sc.get(&d_temp, temp_bytes));
+    BUILD_TRY(rocprim::exclusive_scan(d_temp, temp_bytes, d_flags, d_scan, zero, (size_t)n_slots, ClassPlus(), s));
+    hipLaunchKernelGGL(k_reorder, dim3(grid_for(4ll << max_depth), n_groups), dim3(256), 0, s, set, d_groups, slot0, d_scan, entries, order,
+                       out_planes, out_cubes, out_spheres);
     BUILD_TRY(hipGetLastError());
     return hipStreamSynchronize(s);
 }

@@ -223,6 +223,8 @@ struct rt_ctx {
     int lds_prims = 1;                       // tiny scenes: primitive records in LDS; 1 = shadow kernel only, 2 = extend too
     int device_build = 1;                    // hierarchies and leaf-order records are made on the GPU (rt_set_option)
     int motion_boxes = 1;                    // device-built hierarchies of scenes with moving primitives keep boxes per time
+    int hierarchy_order = 1;                 // records of groups with a second-level hierarchy are stored in hierarchy order
+    bool reorder_active = true;              // ... as the option stood when the current scene was uploaded
     int sub_stride = 4;                      // words (float4) per second-level node: 4, or 8 with boxes per time
     bool built_on_device = false;            // what the current scene's upload used
     long long n_file_nodes = 0, n_file_entries = 0;
@@ -230,6 +232,8 @@ struct rt_ctx {
     double sphere_e = 0.0;                   // rounding allowance of the float sphere test, see rt_upload_scene
     DevBuf<float4> d_sub_nodes_file, d_sub_nodes;   // file-order set alone / file-order set followed by the leaves'
     DevBuf<int> d_sub_entries_file, d_sub_entries, d_prim_ids;
+    DevBuf<int> d_sub_order_file, d_sub_order;      // per entry slot: the primitive's place in the reference's testing order
+    DevBuf<float4> d_walk_planes, d_walk_cubes, d_walk_spheres;   // the file-order set in hierarchy order
 
     // device scene
     DevBuf<float4> d_nodes, d_mats, d_plane_uv, d_plane_bound, d_texels, d_lights, d_verts, d_edges;
@@ -336,6 +340,7 @@ void rt_destroy(rt_ctx* c) {
                               &c->q_a[0], &c->q_a[1], &c->q_b[0], &c->q_b[1], &c->n_a, &c->n_b, &c->n_c, &c->n_col, &c->accum };
     for (auto* b : f4s) b->release();
     c->d_sub_nodes.release(); c->d_sub_entries.release(); c->d_sub_nodes_file.release(); c->d_sub_entries_file.release(); c->d_prim_ids.release();
+    c->d_sub_order_file.release(); c->d_sub_order.release(); c->d_walk_planes.release(); c->d_walk_cubes.release(); c->d_walk_spheres.release();
     c->d_leaves.release(); c->d_tex_desc.release(); c->d_local_tiles.release(); c->n_uv.release(); c->n_pix.release();
     c->link.release(); c->ctr.release(); c->shadow.release(); c->stats.release(); c->out_tmp.release();
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -362,6 +367,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "lds_prims") == 0) { c->lds_prims = (int)value; return RT_OK; }
     if (std::strcmp(name, "device_build") == 0) { c->device_build = value != 0; return RT_OK; }
     if (std::strcmp(name, "motion_boxes") == 0) { c->motion_boxes = value != 0; return RT_OK; }
+    if (std::strcmp(name, "hierarchy_order") == 0) { c->hierarchy_order = value != 0; return RT_OK; }
     if (std::strcmp(name, "graphs") == 0) { c->use_graphs = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "max_grid") == 0) {
         if (value < 0 || value > (1 << 20)) return c->fail(RT_ERR_ARG, "max_grid must be 0..%d", 1 << 20);
@@ -654,6 +660,18 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
         RT_HIP(c, c->d_sub_entries_file.upload(c->h_sub_entries_file, s));
         RT_HIP(c, hipStreamSynchronize(s));
     }
+    // The file-order set as its hierarchy reads it: records in hierarchy order (the file-order arrays themselves stay,
+    // the leaf-order copies are gathered from them by file index).
+    d.walkset = d.fileset; d.sub_order = nullptr;
+    c->reorder_active = c->hierarchy_order != 0;
+    if (c->file_sub_root >= 0 && c->reorder_active) {
+        BuildGroup g{}; g.pn = np; g.cn = nc; g.sn = ns; g.n = np + nc + ns; g.depth = c->file_sub_depth; g.node_base = c->file_sub_root;
+        RT_HIP(c, c->d_walk_planes.resize((size_t)np * 3)); RT_HIP(c, c->d_walk_cubes.resize((size_t)nc * 6)); RT_HIP(c, c->d_walk_spheres.resize((size_t)ns * 2));
+        RT_HIP(c, c->d_sub_order_file.resize((size_t)c->n_file_entries));
+        RT_HIP(c, rt_build_reorder(s, d.fileset, &g, 1, c->d_sub_entries_file.p, c->d_sub_order_file.p, c->d_walk_planes.p, c->d_walk_cubes.p, c->d_walk_spheres.p));
+        d.walkset.planes = c->d_walk_planes.p; d.walkset.cubes = c->d_walk_cubes.p; d.walkset.spheres = c->d_walk_spheres.p;
+        d.sub_order = c->d_sub_order_file.p;
+    }
     float centre[3] = { 0.0f, 0.0f, 0.0f }, radius = 1.0f;
     if (np + nc + ns > 0) {
         float half[3];
@@ -689,6 +707,8 @@ static int upload_bvh_impl(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes,
     DevScene& d = c->scene;
     d.n_nodes = 0; d.n_leaves = 0;
     d.sub_nodes = c->n_file_nodes ? c->d_sub_nodes_file.p : nullptr; d.sub_entries = c->d_sub_entries_file.p;
+    const bool reordered = d.walkset.cubes != d.fileset.cubes || d.walkset.spheres != d.fileset.spheres || d.walkset.planes != d.fileset.planes;
+    d.sub_order = reordered ? c->d_sub_order_file.p : nullptr;
     d.sub_stack_entries = d.sub_stack_entries_leaves = rt_sub_stack_entries(c->file_sub_depth);
     int deepest = c->file_sub_depth, deepest_leaf = 0;
     if (!nodes || n_nodes <= 0) return RT_OK;
@@ -777,6 +797,7 @@ static int upload_bvh_impl(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes,
     DevPrimSet leafset = d.fileset;
     leafset.n_planes = (int)lp_n; leafset.n_cubes = (int)lc_n; leafset.n_spheres = (int)ls_n;
     long long total_nodes = c->n_file_nodes, total_entries = c->n_file_entries;
+    std::vector<BuildGroup> groups;                               // leaves that get a second-level hierarchy
     if (on_device) {
         // leaf-order copies of the records, then one build over all leaves that are large enough
         RT_HIP(c, c->d_prim_ids.resize((size_t)n_prim_ids));
@@ -786,7 +807,7 @@ static int upload_bvh_impl(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes,
         RT_HIP(c, rt_build_gather_leaves(s, d.fileset, c->d_prim_ids.p, gather.data(), (int)gather.size(),
                                          c->d_leaf_planes.p, c->d_leaf_cubes.p, c->d_leaf_spheres.p));
         leafset.planes = c->d_leaf_planes.p; leafset.cubes = c->d_leaf_cubes.p; leafset.spheres = c->d_leaf_spheres.p;
-        std::vector<BuildGroup> groups; long long n_items = 0;
+        long long n_items = 0;
         for (size_t g = 0; g < gather.size(); ++g) {
             const LeafGather& L = gather[g];
             const long long cnt = (long long)L.n_planes + L.n_cubes + L.n_spheres;
@@ -809,7 +830,7 @@ static int upload_bvh_impl(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes,
     } else {
         std::vector<float4> lp, lc, ls;
         std::vector<float4> sub_nodes = c->h_sub_nodes_file;      // the file-order hierarchy keeps its node indices
-        std::vector<int> sub_entries = c->h_sub_entries_file;
+        std::vector<int> sub_entries = c->h_sub_entries_file;     // (replaced below by the device's copy when that was re-ordered)
         std::vector<SubItem> items;
         lp.reserve((size_t)lp_n * 3); lc.reserve((size_t)lc_n * 6); ls.reserve((size_t)ls_n * 2);
         for (size_t g = 0; g < gather.size(); ++g) {
@@ -834,6 +855,9 @@ static int upload_bvh_impl(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes,
                 if (depth > RT_SUB_MAX_DEPTH) return c->fail(RT_ERR_CAPACITY, "second-level hierarchy deeper than %d", RT_SUB_MAX_DEPTH);
                 SubBuilder sb{ sub_nodes, sub_entries };
                 leaves[2 * g + 1].z = sb.build_group(items, depth); leaves[2 * g + 1].w = depth; deepest = std::max(deepest, depth); deepest_leaf = std::max(deepest_leaf, depth);
+                BuildGroup b{}; b.p0 = L.lp0; b.pn = L.n_planes; b.c0 = L.lc0; b.cn = L.n_cubes; b.s0 = L.ls0; b.sn = L.n_spheres;
+                b.n = cnt; b.depth = depth; b.node_base = leaves[2 * g + 1].z;
+                groups.push_back(b);
             }
         }
         total_nodes = (long long)(sub_nodes.size() / 4); total_entries = (long long)sub_entries.size();
@@ -842,8 +866,33 @@ static int upload_bvh_impl(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes,
         RT_HIP(c, c->d_leaf_spheres.upload(ls, s));
         RT_HIP(c, c->d_sub_nodes.upload(sub_nodes, s));
         RT_HIP(c, c->d_sub_entries.upload(sub_entries, s));
+        // the file-order hierarchy's slots as the scene upload left them on the device (re-ordered or not)
+        if (c->n_file_entries) RT_HIP(c, hipMemcpyAsync(c->d_sub_entries.p, c->d_sub_entries_file.p, sizeof(int) * (size_t)c->n_file_entries, hipMemcpyDeviceToDevice, s));
         RT_HIP(c, hipStreamSynchronize(s));
         leafset.planes = c->d_leaf_planes.p; leafset.cubes = c->d_leaf_cubes.p; leafset.spheres = c->d_leaf_spheres.p;
+    }
+    // Leaves with a hierarchy: their records go into hierarchy order (inside the leaf's own ranges of the leaf-order arrays).
+    if (c->reorder_active && (reordered || !groups.empty())) {
+        RT_HIP(c, c->d_sub_order.resize((size_t)std::max<long long>(total_entries, 1)));
+        if (reordered && c->n_file_entries)
+            RT_HIP(c, hipMemcpyAsync(c->d_sub_order.p, c->d_sub_order_file.p, sizeof(int) * (size_t)c->n_file_entries, hipMemcpyDeviceToDevice, s));
+        else if (c->n_file_entries)       // not re-ordered: a slot's entry is its own place in the testing order
+            RT_HIP(c, hipMemcpyAsync(c->d_sub_order.p, c->d_sub_entries_file.p, sizeof(int) * (size_t)c->n_file_entries, hipMemcpyDeviceToDevice, s));
+        if (!groups.empty()) {
+            DevBuf<float4> tp, tc, ts;
+            hipError_t e = tp.resize((size_t)lp_n * 3);
+            if (e == hipSuccess) e = tc.resize((size_t)lc_n * 6);
+            if (e == hipSuccess) e = ts.resize((size_t)ls_n * 2);
+            if (e == hipSuccess && lp_n) e = hipMemcpyAsync(tp.p, leafset.planes, sizeof(float4) * 3 * (size_t)lp_n, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess && lc_n) e = hipMemcpyAsync(tc.p, leafset.cubes, sizeof(float4) * 6 * (size_t)lc_n, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess && ls_n) e = hipMemcpyAsync(ts.p, leafset.spheres, sizeof(float4) * 2 * (size_t)ls_n, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = rt_build_reorder(s, leafset, groups.data(), (int)groups.size(), c->d_sub_entries.p, c->d_sub_order.p, tp.p, tc.p, ts.p);
+            if (e != hipSuccess) { tp.release(); tc.release(); ts.release(); return c->hip(e, "records in hierarchy order"); }
+            std::swap(c->d_leaf_planes, tp); std::swap(c->d_leaf_cubes, tc); std::swap(c->d_leaf_spheres, ts);
+            tp.release(); tc.release(); ts.release();
+            leafset.planes = c->d_leaf_planes.p; leafset.cubes = c->d_leaf_cubes.p; leafset.spheres = c->d_leaf_spheres.p;
+        }
+        d.sub_order = c->d_sub_order.p;
     }
     RT_HIP(c, c->d_nodes.upload(dn, s));
     RT_HIP(c, c->d_leaves.upload(leaves, s));
@@ -1193,12 +1242,14 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         // workgroups of 4 wavefronts): for kernels whose workgroups are cheap to start and whose rounds cost about the
         // same, a second generation of workgroups only adds start-up cost and an uneven tail.  Launches with very many
         // chunks of unequal cost (walks of second-level hierarchies, tens of thousands of chunks of glossy rays) do
-        // better when the dispatcher hands out a second generation as workgroups finish.  Measured per kernel on
+        // better when the dispatcher hands out a second generation as workgroups finish; where chunk costs differ by an
+        // order of magnitude - primary rays through second-level hierarchies, soft-shadow chunks of which some trace every
+        // pair and others none - one workgroup per chunk or two (8192) evens the load out best.  Measured per kernel on
         // scene.json, bvh_vs_unaccel_5, cube_mb and 10^6 primitives; rt_set_option("grid_*") overrides.
         const bool sub = c->scene.sub_nodes != nullptr;
-        const int g_primary = c->grid_primary ? c->grid_primary : ((!sub && c->scene.lds_prims) ? 1024 : 2048);   // 1024: a handful of primitives
+        const int g_primary = c->grid_primary ? c->grid_primary : (sub ? 8192 : (c->scene.lds_prims ? 1024 : 2048));   // 1024: a handful of primitives
         const int g_shade = c->grid_shade ? c->grid_shade : 1024;
-        const int g_shadow = c->grid_shadow ? c->grid_shadow : ((!sub && cfg->soft_shadows && c->fast_samples) ? 1536 : 2048);
+        const int g_shadow = c->grid_shadow ? c->grid_shadow : ((!sub && cfg->soft_shadows && c->fast_samples) ? 8192 : 2048);
         auto g_secondary = [&](int level) {
             if (c->grid_secondary) return c->grid_secondary;
             const long long worst_chunks = (long long)w.regions * w.link_rcap[level] / RT_BLOCK;

@@ -444,6 +444,14 @@ DEVI void sub_child(const SubRay& q, float4 mn, float4 mx, float& tn, float& tf)
     tn = __builtin_fmaf(-1e-6f, m, tn); tf = __builtin_fmaf(1e-6f, m, tf);
 }
 
+// Exact tie between two reported distances: the primitive the reference tests first wins (strict '<' in its loops).
+// sub_order keeps every slot's place in that order; without it the entry itself is the place.  Rarely reached, and kept
+// out of line so that the walk's registers are not held across it.
+__device__ __noinline__ bool tested_earlier(const DevScene& sc, int slot, int best_slot) {
+    const int* __restrict__ ord = sc.sub_order ? sc.sub_order : sc.sub_entries;
+    return (unsigned)ord[slot] < (unsigned)ord[best_slot];
+}
+
 // Layout the walk relies on: a group's hierarchy is a perfect binary tree in heap order (node h of the group sits at
 // root + h, its children at root + 2h + 1 and root + 2h + 2, the levels 0 .. depth - 1 are interior, the children of
 // level depth - 1 are runs), and run j of the group owns the four entry slots 4 * (root + j) .. + 3 (unused slots hold
@@ -455,7 +463,7 @@ template <bool ANY, bool FAST, bool MOTION>
 DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth, const Ray& r, const SubRay& q, bool mb, bool leaf_rule,
                     float stop_below, int* __restrict__ stack, Best& best) {
     float best_t = leaf_rule ? INFINITY : FLT_MAX;
-    unsigned best_key = 0u; bool has = false;
+    int best_slot = 0; bool has = false;
     int sp = 0, h = 0;                                        // h = heap index inside the group
     // Scenes with moving primitives keep boxes per time (8 words per node); rays at time 0 - every secondary ray, and
     // every ray of a frame without motion blur, where primitives stay at their first location - read the first half only.
@@ -506,7 +514,8 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (go4[k] && !(tn4[k] > best_t)) {
-                    const int4 ev = *(const int4*)(sc.sub_entries + 4 * (size_t)(root + kid0 + k - first_run));
+                    const int slot0 = 4 * (root + kid0 + k - first_run);
+                    const int4 ev = *(const int4*)(sc.sub_entries + slot0);
 #pragma unroll
                     for (int e = 0; e < RT_SUB_LEAF; ++e) {
                         const unsigned entry = (unsigned)(e == 0 ? ev.x : e == 1 ? ev.y : e == 2 ? ev.z : ev.w);
@@ -516,8 +525,8 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth
                         if (cls == 0) ok = plane_test<false, FAST>(S.planes + 3 * idx, S.edges, nullptr, r, false, t, nullptr);
                         else if (cls == 1) ok = cube_test<false, FAST>(S.cubes + 6 * idx, r, mb, false, t, nullptr);
                         else ok = sphere_test<false, FAST>(S.spheres + 2 * idx, r, mb, false, t, nullptr);
-                        if (ok && (!leaf_rule || t >= 0.0f) && (t < best_t || (has && t == best_t && entry < best_key))) {
-                            has = true; best_t = t; best_key = entry; best.t = t; best.cls = cls; best.idx = idx;
+                        if (ok && (!leaf_rule || t >= 0.0f) && (t < best_t || (has && t == best_t && tested_earlier(sc, slot0 + e, best_slot)))) {
+                            has = true; best_t = t; best_slot = slot0 + e; best.t = t; best.cls = cls; best.idx = idx;
                             if (ANY || t < stop_below) return true;
                         }
                     }
@@ -574,6 +583,8 @@ DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict_
     const bool mb = f.motion_blur != 0;
     SubRay q; q.rcp = q.cn = q.cf = mk(0.0f, 0.0f, 0.0f); q.px = q.py = q.pz = true;
     if (SUB) q = make_sub_ray(sc, r);
+    // the file-order set as its hierarchy reads it (records in hierarchy order): what best.idx of a file-order hit indexes
+    const DevPrimSet& FS = SUB ? sc.walkset : sc.fileset;
     if (f.use_bvh) {
         int i = 0;
         const int n = sc.n_nodes;
@@ -593,16 +604,17 @@ DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict_
         }
         if (!with_fallback) return false;
         best.fileset = 1;
-        return test_group<false, SUB, FAST>(sc, sc.fileset, r, q, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
+        return test_group<false, SUB, FAST>(sc, FS, r, q, mb, 0, FS.n_planes, 0, FS.n_cubes, 0, FS.n_spheres,
                                  sc.file_sub_root, sc.file_sub_depth, false, stop_below, stack, best);
     }
     best.fileset = 1;
-    return test_group<ANY, SUB, FAST>(sc, sc.fileset, r, q, mb, 0, sc.fileset.n_planes, 0, sc.fileset.n_cubes, 0, sc.fileset.n_spheres,
+    return test_group<ANY, SUB, FAST>(sc, FS, r, q, mb, 0, FS.n_planes, 0, FS.n_cubes, 0, FS.n_spheres,
                            sc.file_sub_root, sc.file_sub_depth, false, stop_below, stack, best);
 }
 
+template <int SUB>
 DEVI void full_hit(const DevScene& sc, const DevFrame& f, const Ray& r, const Best& best, HitOut& h) {
-    const DevPrimSet& S = best.fileset ? sc.fileset : sc.leafset;
+    const DevPrimSet& S = best.fileset ? (SUB ? sc.walkset : sc.fileset) : sc.leafset;
     const bool mb = f.motion_blur != 0;
     float t;
     h.u = 0.0f; h.v = 0.0f;
@@ -822,7 +834,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
         HitOut h; V3 N = mk(0, 0, 1), rd = mk(0, 0, 1), fd = mk(0, 0, 1); float weight = 0.0f, gloss_angle = 0.0f; bool glossy = false;
         if (hit) {
             if (STATS) n_shadow_ref += shadow_per_hit * mult * (unsigned)copies;
-            full_hit(sc, f, r, best, h);
+            full_hit<SUB>(sc, f, r, best, h);
             if (spawn) {
                 float4 m0 = sc.mats[3 * h.gid], m1 = sc.mats[3 * h.gid + 1], m2 = sc.mats[3 * h.gid + 2];
                 float reflectivity = m2.z;                               // raytracer.cpp:374-375, evaluated on the host

@@ -56,12 +56,15 @@ struct DevPrimSet {
 // leaf     : 2 words of ints (plane_first, plane_count, cube_first, cube_count)
 //            (sphere_first, sphere_count, second-level root | -1, depth of that hierarchy)
 // second-level node : 4 words, heap order per group, see sub_trace in rt_kernels.hip; entries: four slots per run,
-//            class << 30 | index in the primitive set, or -1
+//            class << 30 | index in the primitive set, or -1.  The groups' records are stored in hierarchy order (a run's
+//            primitives are neighbours in their class arrays); sub_order keeps, per slot, class << 30 | the index the
+//            primitive had in the reference's testing order, which decides exact ties
 struct DevScene {
     const float4* nodes;  int n_nodes;
     const int4* leaves;   int n_leaves;
     DevPrimSet leafset;
     DevPrimSet fileset;
+    DevPrimSet walkset;            // the file-order set as its second-level hierarchy reads it (records in hierarchy order); = fileset without one
     const float4* mats;
     const float4* plane_uv;
     const float4* plane_bound;     // per plane in file order: sphere around its vertices (centre, radius)
@@ -70,6 +73,7 @@ struct DevScene {
     const float4* lights; int n_lights;
     const float4* sub_nodes;       // second-level hierarchies of all groups (NULL when no group has one)
     const int* sub_entries;
+    const int* sub_order;          // per entry slot: the primitive's place in the reference's testing order (NULL: the entry itself is that)
     int file_sub_root;             // second-level root over the whole file-order set, or -1
     int file_sub_depth;            // depth of that hierarchy
     int sub_stride;                // words per second-level node: 4 (boxes over the whole motion) or 8 (boxes per time, see rt_sub_motion_offset)

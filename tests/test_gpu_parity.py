@@ -285,6 +285,38 @@ def test_second_level_hierarchy_changes_no_pixel(n, res, flags):
     assert np.array_equal(imgs[0], imgs[1])
 
 
+@pytest.mark.parametrize("flags", [[], ["-u"], ["-rd", "2", "-grs", "1"]])
+@pytest.mark.parametrize("device_build", [1, 0])
+def test_records_in_hierarchy_order_keep_the_reference_tie_rule(flags, device_build):
+    """Groups with a hierarchy store their records in hierarchy order, and what decides an exact tie between two
+    reported distances - the primitive tested first by the reference wins (strict '<', bvh.cpp:70-95,
+    raytracer.cpp:202-247) - is kept per entry slot.  Every primitive of this scene exists twice, with identical
+    geometry and different colours, the second copies in shuffled order: every hit is an exact tie.  The frame must
+    equal the one of the plain search (no hierarchy), with the records re-ordered and with the option off."""
+    rng = np.random.default_rng(5)
+    t = sg.random_prims(3000, 21, transparent_frac=0.1, extent=8.0, rmin=0.15, rmax=0.5)
+    twin = t[rng.permutation(len(t))].copy()
+    twin[:, 4:7] = 1.0 - twin[:, 4:7]
+    both = np.concatenate([t[:1500], twin[:1700], t[1500:], twin[1700:]])
+    cfg, _ = api.parse_args(flags)
+    got = []
+    for opts in ({"second_level_min_group": 1 << 40}, {"hierarchy_order": 1}, {"hierarchy_order": 0}):
+        ls = api.ArrayScene(both, (480, 270))
+        r = api.Renderer(0)
+        r.set_option("device_build", device_build)
+        for k, v in opts.items():
+            r.set_option(k, v)
+        r.upload(ls, with_bvh=bool(cfg.bvh))
+        img, st = r.render(cfg)
+        got.append((img, (st.shadow_rays, st.reflection_rays, st.refraction_rays)))
+        r.close(); ls.close()
+    assert got[0][0].max() > 0
+    # the twins' colours differ, so a wrong winner shows
+    assert len(np.unique(got[0][0].reshape(-1, 3), axis=0)) > 100
+    for other in got[1:]:
+        assert np.array_equal(got[0][0], other[0]) and got[0][1] == other[1]
+
+
 @pytest.mark.parametrize("n,flags", [(30000, []), (30000, ["-u"]), (20000, ["-m", "-mbs", "1", "-rd", "2", "-grs", "1"]), (300, ["-rd", "2", "-grs", "1"]), (9, [])])
 def test_device_built_hierarchies_equal_host_built(n, flags):
     """The hierarchies and leaf-order records made on the GPU (Morton sort, perfect trees) and the ones made on the host
