@@ -146,7 +146,18 @@ def self_launch(args) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
     env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "4")
-    return subprocess.run(cmd, env=env).returncode
+    # stdout carries the result line only: whatever else the ranks or the communication library print there goes to stderr
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in child.stdout:
+        is_result = False
+        if line.lstrip().startswith("{"):
+            try:
+                json.loads(line); is_result = True
+            except ValueError:
+                pass
+        (sys.stdout if is_result else sys.stderr).write(line)
+        (sys.stdout if is_result else sys.stderr).flush()
+    return child.wait()
 
 
 def load_counters(workload: str) -> dict:

@@ -1253,7 +1253,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         auto g_secondary = [&](int level) {
             if (c->grid_secondary) return c->grid_secondary;
             const long long worst_chunks = (long long)w.regions * w.link_rcap[level] / RT_BLOCK;
-            return (sub || worst_chunks > 16384) ? 2048 : 1024;
+            return sub ? 8192 : (worst_chunks > 16384 ? 2048 : 1024);
         };
         const int grid0 = std::max(1, std::min(g_primary, chunks0_batch));
         for (int smp = 0; smp < S; ++smp) {
