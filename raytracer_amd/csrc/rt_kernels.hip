@@ -463,6 +463,10 @@ template <bool ANY, bool FAST, bool MOTION>
 DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth, const Ray& r, const SubRay& q, bool mb, bool leaf_rule,
                     float stop_below, int* __restrict__ stack, Best& best) {
     float best_t = leaf_rule ? INFINITY : FLT_MAX;
+    // what a subtree must be entered below to be worth a visit: the best distance so far - or, once a caller who only
+    // asks "is the closest distance below stop_below" has a hit at or beyond that value, stop_below itself (nothing
+    // entered later than that can change the answer; which primitive is reported is then not the caller's concern)
+    float prune_t = best_t;
     int best_slot = 0; bool has = false;
     int sp = 0, h = 0;                                        // h = heap index inside the group
     // Scenes with moving primitives keep boxes per time (8 words per node); rays at time 0 - every secondary ray, and
@@ -506,14 +510,14 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth
             float tn = 0.0f, tf = 0.0f;
             if (k < 2 || wide) sub_child(q, bx[2 * k], bx[2 * k + 1], tn, tf);
             // skip only on a certain miss; any NaN makes the comparisons false and the child is visited
-            go4[k] = (k < 2 || wide) && !(tn > tf) && !(tf < 0.0f) && !(tn > best_t);
+            go4[k] = (k < 2 || wide) && !(tn > tf) && !(tf < 0.0f) && !(tn > prune_t);
             tn4[k] = tn;
         }
         if (runs) {
             // entry runs are tested on the spot
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (go4[k] && !(tn4[k] > best_t)) {
+                if (go4[k] && !(tn4[k] > prune_t)) {
                     const int slot0 = 4 * (root + kid0 + k - first_run);
                     const int4 ev = *(const int4*)(sc.sub_entries + slot0);
 #pragma unroll
@@ -528,6 +532,7 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth
                         if (ok && (!leaf_rule || t >= 0.0f) && (t < best_t || (has && t == best_t && tested_earlier(sc, slot0 + e, best_slot)))) {
                             has = true; best_t = t; best_slot = slot0 + e; best.t = t; best.cls = cls; best.idx = idx;
                             if (ANY || t < stop_below) return true;
+                            prune_t = (stop_below > -INFINITY) ? stop_below : t;       // t >= stop_below here
                         }
                     }
                 }
