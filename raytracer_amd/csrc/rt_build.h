@@ -47,4 +47,10 @@ struct LeafGather { int first_id, n_planes, n_cubes, n_spheres, lp0, lc0, ls0, p
 hipError_t rt_build_gather_leaves(hipStream_t s, const DevPrimSet& fileset, const int* prim_ids_dev, const LeafGather* leaves, int n_leaves,
                                   float4* leaf_planes, float4* leaf_cubes, float4* leaf_spheres);
 
+// Radix sort of (key, value) pairs on the low `bits` bits of the keys (rocPRIM), out of place.  rt_sort_pairs_temp_bytes
+// tells how much temporary device memory a sort of n pairs needs; rt_sort_pairs only enqueues work on the stream.
+hipError_t rt_sort_pairs_temp_bytes(size_t n, size_t* bytes);
+hipError_t rt_sort_pairs(hipStream_t s, void* temp, size_t temp_bytes, const unsigned* keys_in, unsigned* keys_out, const unsigned* vals_in, unsigned* vals_out,
+                         size_t n, int bits);
+
 #endif

@@ -586,3 +586,14 @@ hipError_t rt_build_reorder(hipStream_t s, const DevPrimSet& set, const BuildGro
     BUILD_TRY(hipGetLastError());
     return hipStreamSynchronize(s);
 }
+
+hipError_t rt_sort_pairs_temp_bytes(size_t n, size_t* bytes) {
+    *bytes = 0;
+    return rocprim::radix_sort_pairs(nullptr, *bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr, n, 0u, 32u, (hipStream_t)nullptr);
+}
+
+hipError_t rt_sort_pairs(hipStream_t s, void* temp, size_t temp_bytes, const unsigned* keys_in, unsigned* keys_out, const unsigned* vals_in, unsigned* vals_out,
+                         size_t n, int bits) {
+    if (n == 0) return hipSuccess;
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, (unsigned)bits, s);
+}

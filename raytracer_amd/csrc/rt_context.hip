@@ -225,6 +225,9 @@ struct rt_ctx {
     int motion_boxes = 1;                    // device-built hierarchies of scenes with moving primitives keep boxes per time
     int hierarchy_order = 1;                 // records of groups with a second-level hierarchy are stored in hierarchy order
     bool reorder_active = true;              // ... as the option stood when the current scene was uploaded
+    int sort_rays = 1;                       // scenes with second-level hierarchies: secondary rays are sorted by origin cell and direction before they are traced
+    DevBuf<unsigned> sort_keys[2], sort_slots[2];
+    DevBuf<unsigned char> sort_temp;
     int sub_stride = 4;                      // words (float4) per second-level node: 4, or 8 with boxes per time
     bool built_on_device = false;            // what the current scene's upload used
     long long n_file_nodes = 0, n_file_entries = 0;
@@ -340,6 +343,8 @@ void rt_destroy(rt_ctx* c) {
                               &c->q_a[0], &c->q_a[1], &c->q_b[0], &c->q_b[1], &c->n_a, &c->n_b, &c->n_c, &c->n_col, &c->accum };
     for (auto* b : f4s) b->release();
     c->d_sub_nodes.release(); c->d_sub_entries.release(); c->d_sub_nodes_file.release(); c->d_sub_entries_file.release(); c->d_prim_ids.release();
+    for (int k = 0; k < 2; ++k) { c->sort_keys[k].release(); c->sort_slots[k].release(); }
+    c->sort_temp.release();
     c->d_sub_order_file.release(); c->d_sub_order.release(); c->d_walk_planes.release(); c->d_walk_cubes.release(); c->d_walk_spheres.release();
     c->d_leaves.release(); c->d_tex_desc.release(); c->d_local_tiles.release(); c->n_uv.release(); c->n_pix.release();
     c->link.release(); c->ctr.release(); c->shadow.release(); c->stats.release(); c->out_tmp.release();
@@ -368,6 +373,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "device_build") == 0) { c->device_build = value != 0; return RT_OK; }
     if (std::strcmp(name, "motion_boxes") == 0) { c->motion_boxes = value != 0; return RT_OK; }
     if (std::strcmp(name, "hierarchy_order") == 0) { c->hierarchy_order = value != 0; return RT_OK; }
+    if (std::strcmp(name, "sort_rays") == 0) { c->sort_rays = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "graphs") == 0) { c->use_graphs = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "max_grid") == 0) {
         if (value < 0 || value > (1 << 20)) return c->fail(RT_ERR_ARG, "max_grid must be 0..%d", 1 << 20);
@@ -1168,6 +1174,13 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     const size_t cap_nodes = plan.cap_nodes, cap_links = plan.cap_links, cap_rays = plan.cap_rays, cap_pix = plan.cap_pix;
     const long long* node_off = plan.node_off; const long long* link_off = plan.link_off; const long long* rcap = plan.rcap;
 
+    // Scenes with second-level hierarchies: the rays of every level >= 1 are sorted by origin cell and direction before
+    // they are traced (k_sort_keys).  The sort runs over the level's whole queue, so it is only used while that queue is
+    // of the order of the batch itself (not for fan-outs whose worst case dwarfs the rays that exist).
+    const bool sorting = !noalloc && c->sort_rays && c->scene.sub_nodes != nullptr && D >= 1 && plan.fanout && cap_rays <= 8 * (size_t)B + 4096;
+    size_t sort_temp_bytes = 0;
+    if (sorting) RT_HIP(c, rt_sort_pairs_temp_bytes(cap_rays, &sort_temp_bytes));
+
     DevWork w; std::memset(&w, 0, sizeof w);
     if (noalloc) {
         // carve the scratch block: fixed part first, then the batch buffers (sizes as in plan_bytes)
@@ -1186,7 +1199,8 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         if ((size_t)(q - arena) > RT_NOALLOC_BYTES) return c->fail(RT_ERR_CAPACITY, "rt_render_device_noalloc: work plan exceeds the scratch array");
     } else {
         const bool grow = cap_nodes > c->n_a.n || plan.cap_slots > c->n_col.n || cap_links > c->link.n || cap_rays > c->q_a[0].n || (size_t)n_slots > c->accum.n ||
-                          (f.textures && cap_nodes > c->n_uv.n) || plan.cap_shadow > c->shadow.n || cap_pix > c->n_pix.n;
+                          (f.textures && cap_nodes > c->n_uv.n) || plan.cap_shadow > c->shadow.n || cap_pix > c->n_pix.n ||
+                          (sorting && (cap_rays > c->sort_keys[0].n || sort_temp_bytes > c->sort_temp.n));
         if (grow) {
             // Recorded frames hold the addresses of the buffers that are about to be freed: drop every recording before any
             // reallocation, and wait for the frames still in flight on either stream.
@@ -1201,6 +1215,10 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         RT_HIP(c, c->n_pix.resize(cap_pix));
         RT_HIP(c, c->shadow.resize(plan.cap_shadow));
         RT_HIP(c, c->link.resize(cap_links));
+        if (sorting) {
+            for (int q = 0; q < 2; ++q) { RT_HIP(c, c->sort_keys[q].resize(cap_rays)); RT_HIP(c, c->sort_slots[q].resize(cap_rays)); }
+            RT_HIP(c, c->sort_temp.resize(sort_temp_bytes));
+        }
         RT_HIP(c, c->accum.resize((size_t)n_slots));
         RT_HIP(c, c->ctr.resize(RT_C_TOTAL));
         RT_HIP(c, c->stats.resize(RT_S_TOTAL));
@@ -1262,6 +1280,14 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
             if (!grouped) RT_HIP(c, hipMemsetAsync(w.shadow, 0, plan.cap_shadow * sizeof(float), s));
             for (int level = 0; level <= D; ++level) {
                 tm->begin(level == 0 ? ST_EXTEND_PRIMARY : ST_EXTEND_SECONDARY);
+                w.perm = nullptr;
+                const size_t n_queue = level >= 1 ? (size_t)w.regions * (size_t)w.link_rcap[level] : 0;
+                if (sorting && n_queue > 0) {
+                    rt_launch_sort_keys(s, c->scene, w, level, c->sort_keys[0].p, c->sort_slots[0].p);
+                    RT_HIP(c, rt_sort_pairs(s, c->sort_temp.p, c->sort_temp.n, c->sort_keys[0].p, c->sort_keys[1].p, c->sort_slots[0].p, c->sort_slots[1].p,
+                                            n_queue, 30));
+                    w.perm = c->sort_slots[1].p;
+                }
                 rt_launch_extend(s, c->scene, f, w, level, level == 0 ? grid0 : g_secondary(level));
                 tm->end();
                 if (level == 0 && split) {
@@ -1324,7 +1350,9 @@ int rt_render_device(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev, rt_stat
     const long long spp = (long long)(cfg->anti_aliasing ? cfg->aa_samples : 1) * (cfg->dof ? cfg->dof_samples : 1) *
                           (cfg->motion_blur ? cfg->mb_samples : 1);
     bool remember = false;
-    if (!stats && c->use_graphs && spp >= 1 && spp <= 64) {
+    // (frames that sort their secondary rays are long and enqueue a library's sort per level: they are not recorded)
+    const bool sorts = c->sort_rays && c->scene.sub_nodes != nullptr && cfg->reflect_refract_depth >= 1;
+    if (!stats && c->use_graphs && spp >= 1 && spp <= 64 && !sorts) {
         rt_ctx::FrameGraph* g = nullptr;
         for (auto& e : c->graphs)
             if (e.out == rgb_out_dev && e.stream == c->stream && e.generation == c->generation && std::memcmp(&e.cfg, cfg, sizeof *cfg) == 0) { g = &e; break; }

@@ -788,11 +788,14 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
     const int link_out = w.link_off[level + 1], link_cap = w.link_rcap[level + 1];
     // queue slot of this thread's ray in chunk g, or -1 past the end of the chunk's region (region returned in rg)
     int seg = 0;
+    // (with w.perm: the k-th ray traced of a region is the one in slot perm[k of that region], see k_sort_keys)
     auto locate = [&](int g, int& rg) -> int {
         while (seg < w.regions - 1 && g >= __builtin_amdgcn_readfirstlane(s_pre[seg + 1])) ++seg;
         rg = seg;
         const int local = (g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * RT_BLOCK + (int)threadIdx.x;
-        return local < __builtin_amdgcn_readfirstlane(s_cnt[seg]) ? seg * w.link_rcap[level] + local : -1;
+        if (!(local < __builtin_amdgcn_readfirstlane(s_cnt[seg]))) return -1;
+        const int at = seg * w.link_rcap[level] + local;
+        return (SUB && w.perm) ? (int)w.perm[at] : at;
     };
     const float4* __restrict__ qa_in = w.q_a[level & 1];
     const float4* __restrict__ qb_in = w.q_b[level & 1];
@@ -1412,6 +1415,40 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, Dev
     if (f.count_stats) block_stat_add(&w.stats[RT_S_NODES], n_shaded, s_tmp);
 }
 
+// Secondary rays of crowded scenes, re-coalesced before they are traced.  The rays a level queues sit in the order their
+// parents were traced; neighbouring lanes then start at unrelated points and walk unrelated parts of the second-level
+// hierarchies (a wavefront of such rays costs two to three times one of neighbouring rays).  This kernel gives every
+// queue slot of `level` a key - region | cell of the origin (Morton code of a 256^3 grid over the scene) | octant of the
+// direction - and one radix sort of (key, slot) per level puts rays that start close together and head the same way
+// side by side; k_extend then takes its k-th ray from slot perm[k].  (Other arrangements of the key's fields - octant
+// first, octant between coarse and fine cell bits - measured within 2 % of this one.)  Regions stay intact (the key's top bits), slots past a region's count sort
+// behind its rays.  Only the order of tracing changes: values never depend on it.
+__global__ __launch_bounds__(RT_BLOCK) void k_sort_keys(DevScene sc, DevWork w, int level, unsigned* __restrict__ keys, unsigned* __restrict__ slots) {
+    const int rcap = w.link_rcap[level];
+    const long long n = (long long)w.regions * rcap;
+    const float4* __restrict__ qa = w.q_a[level & 1];
+    const float4* __restrict__ qb = w.q_b[level & 1];
+    const float lo_x = sc.center[0] - sc.radius, lo_y = sc.center[1] - sc.radius, lo_z = sc.center[2] - sc.radius;
+    const float scale = 256.0f / fmaxf(2.0f * sc.radius, 1e-30f);
+    auto spread = [](unsigned v) -> unsigned {            // 8 bits -> every third bit
+        v = (v | (v << 16)) & 0x0300F00Fu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u;
+        return v;
+    };
+    for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (long long)gridDim.x * blockDim.x) {
+        const int rg = (int)(s / rcap), local = (int)(s - (long long)rg * rcap);
+        unsigned key = ((unsigned)rg << 27) | 0x07FFFFFFu;
+        if (local < min(w.ctr[RT_CTR_LINK(level, rg)], rcap)) {
+            const float4 a = qa[s], b = qb[s];
+            auto cell = [&](float o, float lo) -> unsigned { const float q = (o - lo) * scale; return q > 0.0f ? (q < 255.0f ? (unsigned)q : 255u) : 0u; };   // NaN -> 0
+            const unsigned m = spread(cell(a.x, lo_x)) | (spread(cell(a.y, lo_y)) << 1) | (spread(cell(a.z, lo_z)) << 2);   // 24 bits
+            const unsigned oct = (a.w < 0.0f ? 1u : 0u) | (b.x < 0.0f ? 2u : 0u) | (b.y < 0.0f ? 4u : 0u);
+            key = ((unsigned)rg << 27) | (m << 3) | oct;
+            if (key == (((unsigned)rg << 27) | 0x07FFFFFFu)) --key;              // the one key reserved for empty slots
+        }
+        keys[s] = key; slots[s] = (unsigned)s;
+    }
+}
+
 // raytracer.cpp:171-178: average over the samples and truncate to 0..255.
 __global__ void k_finalize(DevFrame f, DevWork w, unsigned char* __restrict__ out, int tile_major, int n_slots, int samples) {
     const float inv = 1.0f / (float)samples;
@@ -1512,6 +1549,12 @@ void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, cons
     else if (sc.lds_prims) RT_SHADOW_LAUNCH(0, true);
     else RT_SHADOW_LAUNCH(0, false);
 #undef RT_SHADOW_LAUNCH
+}
+
+void rt_launch_sort_keys(hipStream_t s, const DevScene& sc, const DevWork& w, int level, unsigned* keys, unsigned* slots) {
+    const long long n = (long long)w.regions * w.link_rcap[level];
+    long long grid = (n + RT_BLOCK - 1) / RT_BLOCK; if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_sort_keys, dim3((unsigned)grid), dim3(RT_BLOCK), 0, s, sc, w, level, keys, slots);
 }
 
 void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {

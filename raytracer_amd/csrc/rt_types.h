@@ -136,6 +136,7 @@ struct DevWork {
     float4* n_a; float4* n_b; float4* n_c; float2* n_uv; float4* n_col; int* n_pix;
     float* shadow;
     int* link;
+    const unsigned* perm;          // queue slots of the level about to be traced in the order they are traced (see k_sort_keys), or NULL = slot order
     float4* accum;                 // per local pixel slot: running colour sum over samples
     int* ctr;                      // counters, see below
     unsigned long long* stats;     // ray counters, see below
@@ -185,6 +186,7 @@ static inline int rt_sub_stack_entries(int depth) { return 3 * ((depth + 1) / 2)
 // kernel launchers (rt_kernels.hip)
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);
 void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid);
+void rt_launch_sort_keys(hipStream_t s, const DevScene& sc, const DevWork& w, int level, unsigned* keys, unsigned* slots);
 void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);
 void rt_launch_begin_frame(hipStream_t s, const DevWork& w, void* zero, size_t zero_bytes, bool zero_stats);
 void rt_launch_finalize(hipStream_t s, const DevFrame& f, const DevWork& w, unsigned char* out, int tile_major, int n_slots, int samples);

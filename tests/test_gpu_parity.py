@@ -317,6 +317,28 @@ def test_records_in_hierarchy_order_keep_the_reference_tie_rule(flags, device_bu
         assert np.array_equal(got[0][0], other[0]) and got[0][1] == other[1]
 
 
+@pytest.mark.parametrize("flags,moving", [(["-rd", "2", "-grs", "1"], False), (["-r", "-gr", "-grs", "3", "-rd", "2"], False),
+                                          (["-m", "-mbs", "2", "-r", "-gr", "-grs", "2", "-ss", "-sss", "4"], "xyz"), (["-u", "-rd", "3", "-grs", "1"], False)])
+def test_sorted_secondary_rays_change_no_pixel(flags, moving):
+    """Scenes with second-level hierarchies sort the secondary rays of every level by origin cell and direction before
+    tracing them.  Only the order of tracing changes: frames and ray counts equal those of the unsorted queues, on one
+    batch and on several (a small workspace)."""
+    table = sg.random_prims(20000, 13, transparent_frac=0.2, extent=10.0, rmin=0.05, rmax=0.3, moving=bool(moving))
+    cfg, _ = api.parse_args(flags)
+    got = []
+    for sort_rays, workspace in ((1, 0), (0, 0), (1, 16 << 20)):
+        ls = api.ArrayScene(table, (480, 270), moving=moving)
+        r = api.Renderer(0, workspace)
+        r.set_option("sort_rays", sort_rays)
+        r.upload(ls, with_bvh=bool(cfg.bvh))
+        img, st = r.render(cfg)
+        got.append((img, (st.shadow_rays, st.reflection_rays, st.refraction_rays, st.nodes_shaded), st.batches))
+        r.close(); ls.close()
+    assert got[0][0].max() > 0 and got[0][1][1] > 10000 and got[2][2] > got[0][2]
+    for other in got[1:]:
+        assert np.array_equal(got[0][0], other[0]) and got[0][1] == other[1]
+
+
 @pytest.mark.parametrize("n,flags", [(30000, []), (30000, ["-u"]), (20000, ["-m", "-mbs", "1", "-rd", "2", "-grs", "1"]), (300, ["-rd", "2", "-grs", "1"]), (9, [])])
 def test_device_built_hierarchies_equal_host_built(n, flags):
     """The hierarchies and leaf-order records made on the GPU (Morton sort, perfect trees) and the ones made on the host

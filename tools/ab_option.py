@@ -18,10 +18,12 @@ ap.add_argument("--workload", default="config3")
 ap.add_argument("--set", action="append", default=[], help="comma-separated name=value options of one variant")
 ap.add_argument("--n", type=int, default=0)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--fallback", type=int, default=0, help="rt_config.fallback: 2 = no retry of secondary rays after a BVH miss (not the reference's image)")
 args = ap.parse_args()
 wl = bench.WORKLOADS[args.workload]
 W, H = wl["res"]
 cfg, _ = api.parse_args(wl["flags"])
+cfg.fallback = args.fallback
 if wl["scene"] == "ref":
     ls = api.LoadedScene(cases.reference_scene(W, H), cfg, str(cases.TEXTURES))
 elif wl["scene"].startswith("blend:"):
