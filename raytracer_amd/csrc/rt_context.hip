@@ -226,6 +226,7 @@ struct rt_ctx {
     int hierarchy_order = 1;                 // records of groups with a second-level hierarchy are stored in hierarchy order
     bool reorder_active = true;              // ... as the option stood when the current scene was uploaded
     int sort_rays = 1;                       // scenes with second-level hierarchies: secondary rays are sorted by origin cell and direction before they are traced
+    long long sort_rays_min_prims = 2000000; // ... when the scene has at least this many primitives (see enqueue_frame)
     DevBuf<unsigned> sort_keys[2], sort_slots[2];
     DevBuf<unsigned char> sort_temp;
     int sub_stride = 4;                      // words (float4) per second-level node: 4, or 8 with boxes per time
@@ -374,6 +375,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "motion_boxes") == 0) { c->motion_boxes = value != 0; return RT_OK; }
     if (std::strcmp(name, "hierarchy_order") == 0) { c->hierarchy_order = value != 0; return RT_OK; }
     if (std::strcmp(name, "sort_rays") == 0) { c->sort_rays = value != 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "sort_rays_min_prims") == 0) { c->sort_rays_min_prims = value < 0 ? 0 : value; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "graphs") == 0) { c->use_graphs = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "max_grid") == 0) {
         if (value < 0 || value > (1 << 20)) return c->fail(RT_ERR_ARG, "max_grid must be 0..%d", 1 << 20);
@@ -1176,8 +1178,12 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
 
     // Scenes with second-level hierarchies: the rays of every level >= 1 are sorted by origin cell and direction before
     // they are traced (k_sort_keys).  The sort runs over the level's whole queue, so it is only used while that queue is
-    // of the order of the batch itself (not for fan-outs whose worst case dwarfs the rays that exist).
-    const bool sorting = !noalloc && c->sort_rays && c->scene.sub_nodes != nullptr && D >= 1 && plan.fanout && cap_rays <= 8 * (size_t)B + 4096;
+    // of the order of the batch itself (not for fan-outs whose worst case dwarfs the rays that exist), and it costs a few
+    // tenths of a millisecond per level whatever the count: measured, it pays where the scene's records no longer fit
+    // the 256 MB memory-side cache (10^7 primitives: 18 % of the frame), changes nothing at 10^6 primitives and costs
+    // 12 % of a 1080p frame of 20 000 - hence the threshold on the primitive count (rt_set_option).
+    const bool sorts_scene = c->sort_rays && c->scene.sub_nodes != nullptr && (long long)c->np + c->nc + c->ns >= c->sort_rays_min_prims;
+    const bool sorting = !noalloc && sorts_scene && D >= 1 && plan.fanout && cap_rays <= 8 * (size_t)B + 4096;
     size_t sort_temp_bytes = 0;
     if (sorting) RT_HIP(c, rt_sort_pairs_temp_bytes(cap_rays, &sort_temp_bytes));
 
@@ -1351,7 +1357,7 @@ int rt_render_device(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev, rt_stat
                           (cfg->motion_blur ? cfg->mb_samples : 1);
     bool remember = false;
     // (frames that sort their secondary rays are long and enqueue a library's sort per level: they are not recorded)
-    const bool sorts = c->sort_rays && c->scene.sub_nodes != nullptr && cfg->reflect_refract_depth >= 1;
+    const bool sorts = c->sort_rays && c->scene.sub_nodes != nullptr && (long long)c->np + c->nc + c->ns >= c->sort_rays_min_prims && cfg->reflect_refract_depth >= 1;
     if (!stats && c->use_graphs && spp >= 1 && spp <= 64 && !sorts) {
         rt_ctx::FrameGraph* g = nullptr;
         for (auto& e : c->graphs)

@@ -330,6 +330,7 @@ def test_sorted_secondary_rays_change_no_pixel(flags, moving):
         ls = api.ArrayScene(table, (480, 270), moving=moving)
         r = api.Renderer(0, workspace)
         r.set_option("sort_rays", sort_rays)
+        r.set_option("sort_rays_min_prims", 0)                 # (by default only scenes of millions of primitives sort)
         r.upload(ls, with_bvh=bool(cfg.bvh))
         img, st = r.render(cfg)
         got.append((img, (st.shadow_rays, st.reflection_rays, st.refraction_rays, st.nodes_shaded), st.batches))

@@ -19,8 +19,11 @@ ap.add_argument("--set", action="append", default=[], help="comma-separated name
 ap.add_argument("--n", type=int, default=0)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--fallback", type=int, default=0, help="rt_config.fallback: 2 = no retry of secondary rays after a BVH miss (not the reference's image)")
+ap.add_argument("--flags", default=None, help="render flags instead of the workload's own, e.g. --flags='-r -rd 4'")
 args = ap.parse_args()
-wl = bench.WORKLOADS[args.workload]
+wl = dict(bench.WORKLOADS[args.workload])
+if args.flags is not None:
+    wl["flags"] = args.flags.split()
 W, H = wl["res"]
 cfg, _ = api.parse_args(wl["flags"])
 cfg.fallback = args.fallback
