@@ -582,7 +582,9 @@ DEVI bool test_group(const DevScene& sc, const DevPrimSet& S, const Ray& r, cons
 // with_fallback: raytracer.cpp:424,484 - a secondary ray that misses the BVH is retried over every primitive.
 // stop_below (see test_prims) ends the search inside the one group whose result the reference would return: a leaf
 // that yields any hit ends the reference's walk too, so nothing is skipped that could change "closest < stop_below".
-template <bool ANY, int SUB, bool FAST = false>
+// TOGETHER (see the first-level loop): for wavefronts of unrelated rays; primary rays, whose lanes meet the same leaves at
+// the same time anyway, keep the plain loop (and its register allocation).
+template <bool ANY, int SUB, bool FAST = false, bool TOGETHER = true>
 DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict__ nodes, const int4* __restrict__ leaves,
                 int* __restrict__ stack, const Ray& r, bool with_fallback, Best& best, float stop_below = -INFINITY) {
     const bool mb = f.motion_blur != 0;
@@ -597,14 +599,34 @@ DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict_
         const float ax = fabsf(r.d.x), ay = fabsf(r.d.y), az = fabsf(r.d.z);
         const bool fast_ok = ax > 1e-18f && ax < 1e18f && ay > 1e-18f && ay < 1e18f && az > 1e-18f && az < 1e18f;
         const V3 rcp = mk(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
-        while (i < n) {
-            float4 a = nodes[2 * i], b = nodes[2 * i + 1];
-            if (!slab<FAST>(r, a, b, rcp, fast_ok)) { i = f2i(a.w); continue; }
-            int leaf = f2i(b.w);
-            ++i;
-            if (leaf >= 0) {
-                int4 l0 = leaves[2 * leaf], l1 = leaves[2 * leaf + 1];
+        if (SUB && TOGETHER) {
+            // Leaves cost a walk through their own hierarchy, boxes a few instructions.  Every lane first advances to the
+            // next leaf whose box it pierces (lanes differ in how many boxes that takes), then the lanes search their
+            // leaves side by side: a wavefront of unrelated rays makes as many searches as its busiest lane, not one per
+            // position of the node array at which any of its lanes meets a leaf.
+            for (;;) {
+                int leaf = -1;
+                while (i < n) {
+                    const float4 a = nodes[2 * i], b = nodes[2 * i + 1];
+                    if (!slab<FAST>(r, a, b, rcp, fast_ok)) { i = f2i(a.w); continue; }
+                    ++i;
+                    leaf = f2i(b.w);
+                    if (leaf >= 0) break;
+                }
+                if (leaf < 0) break;
+                const int4 l0 = leaves[2 * leaf], l1 = leaves[2 * leaf + 1];
                 if (test_group<ANY, SUB, FAST>(sc, sc.leafset, r, q, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, true, stop_below, stack, best)) { best.fileset = 0; return true; }
+            }
+        } else {
+            while (i < n) {
+                float4 a = nodes[2 * i], b = nodes[2 * i + 1];
+                if (!slab<FAST>(r, a, b, rcp, fast_ok)) { i = f2i(a.w); continue; }
+                int leaf = f2i(b.w);
+                ++i;
+                if (leaf >= 0) {
+                    int4 l0 = leaves[2 * leaf], l1 = leaves[2 * leaf + 1];
+                    if (test_group<ANY, SUB, FAST>(sc, sc.leafset, r, q, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, true, stop_below, stack, best)) { best.fileset = 0; return true; }
+                }
             }
         }
         if (!with_fallback) return false;
@@ -836,7 +858,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
         }
         if (STATS && PRIMARY && active) ++n_primary;
         Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
-        bool hit = active && trace<false, SUB>(sc, f, s_nodes, s_leaves, s_stack, r, !PRIMARY && f.fallback_full, best);
+        bool hit = active && trace<false, SUB, false, !PRIMARY>(sc, f, s_nodes, s_leaves, s_stack, r, !PRIMARY && f.fallback_full, best);
 
         int n_children = 0, n_reflect = 0, n_entries = 0; bool refract = false;   // n_reflect: child colours summed at resolve; n_entries: rays queued for them
         HitOut h; V3 N = mk(0, 0, 1), rd = mk(0, 0, 1), fd = mk(0, 0, 1); float weight = 0.0f, gloss_angle = 0.0f; bool glossy = false;
