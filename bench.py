@@ -207,13 +207,17 @@ def roofline(st, workload: str, small_scene: bool) -> dict:
             for extra in ("SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_INSTS_VMEM_RD"):
                 if c.get(extra):
                     k[extra + "_per_launch"] = c[extra]
+    # the whole frame against the vector ALUs: every kernel's executing time (SQ_ACTIVE_INST_VALU, committed counter pass)
+    # x its launches, as a share of one frame alone and - filled in by the caller - of a frame's share of the timed region
+    frame_busy_s = sum(ctr[n]["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * 2.4e9) * max(1, k["launches"])
+                       for n, k in kernels.items() if n in ctr and ctr[n].get("SQ_ACTIVE_INST_VALU"))
     dom = max(kernels, key=lambda n: kernels[n]["ms"])
     d = kernels[dom]
     alg = {"achieved_GBps": d["GBps"], "peak_GBps": HBM_PEAK_GBS, "frac": d["GBps"] / HBM_PEAK_GBS, "bytes_per_launch": d["bytes_per_launch"],
            "note": "prescribed per-ray record bytes x rays of the launch / launch duration; this implementation moves fewer bytes "
                    "(primary rays are generated in registers, shadow rays are never stored)"}
     traffic = d.get("hbm_bytes_per_launch")
-    out = {"kernel": dom, "avg_launch_ms": d["avg_launch_ms"], "traffic": traffic,
+    out = {"kernel": dom, "avg_launch_ms": d["avg_launch_ms"], "traffic": traffic, "frame_valu_busy_ms": frame_busy_s * 1e3 if frame_busy_s else None,
            "traffic_ratio": (traffic / d["bytes_per_launch"]) if (traffic and d["bytes_per_launch"]) else None,
            "hbm_algorithmic": alg, "l2_hit_rate": d.get("l2_hit_rate"), "by_kernel": kernels}
     if small_scene and "valu_issue_frac" in d:
@@ -578,6 +582,11 @@ def main():
         }
         ceiling = copy_ceiling_GBps(torch, dev)
         line["roofline"]["measured_copy_GBps"] = ceiling
+        busy_ms = line["roofline"].get("frame_valu_busy_ms")
+        if busy_ms:
+            # vector ALUs executing, whole frame: alone, and with the frames in flight of the timed region
+            line["roofline"]["frame_valu_busy_frac_alone"] = busy_ms / head["frame_ms_alone"]
+            line["roofline"]["frame_valu_busy_frac_in_flight"] = busy_ms / head["ms_per_step"]
         if big is not None:
             big.pop("stats")
             line["scaling_4k"] = {"metric": "rays/sec (all ray types), 4K multi-sample frame", "unit": "rays/s", "n_gpus": world,
