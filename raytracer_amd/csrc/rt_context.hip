@@ -217,6 +217,7 @@ struct rt_ctx {
     // 0 = chosen per launch (see enqueue_frame)
     int grid_primary = 0, grid_secondary = 0, grid_shadow = 0, grid_shade = 0;
     bool cull_cones = true;                  // see k_shadow: soft-shadow cones that miss every primitive are not traced
+    bool cull_own = true;                    // ... where a sphere or cube is left out for the rays that leave its own surface outwards
     bool bundle_reflections = true;          // ... as one traced ray with gr_samples hit records (off: gr_samples traced rays)
     bool replicate_reflections = true;       // soft shadows: first reflections traced gr_samples times, each with its own shadow samples
     bool fast_samples = true;                // soft-shadow sample rays: hardware reciprocals instead of IEEE division
@@ -392,6 +393,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "count_rays") == 0) { c->count_rays = value != 0; return RT_OK; }
     if (std::strcmp(name, "fast_samples") == 0) { c->fast_samples = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "cull_cones") == 0) { c->cull_cones = value != 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "cull_own") == 0) { c->cull_own = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "bundle_reflections") == 0) { c->bundle_reflections = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "replicate_reflections") == 0) { c->replicate_reflections = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "overlap") == 0) { c->overlap = value != 0; c->drop_graphs(); return RT_OK; }
@@ -1135,7 +1137,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     int fb = cfg->fallback; if (fb == 0) fb = 1;
     f.fallback_full = (fb == 1);
     f.light_radius = cfg->light_radius; f.seed = cfg->seed; f.fast_samples = c->fast_samples ? 1 : 0; f.count_stats = count_stats ? 1 : 0; f.skip_unlit = c->skip_unlit ? 1 : 0;
-    f.cull_cones = c->cull_cones ? 1 : 0;
+    f.cull_cones = c->cull_cones ? 1 : 0; f.cull_own = c->cull_own ? 1 : 0;
     f.replicate = (cfg->soft_shadows && c->replicate_reflections) ? 1 : 0;
     // identical reflection rays are traced once and recorded gr_samples times (the packed hit record holds 12-bit copy numbers)
     f.bundle = (f.replicate && !cfg->glossy_reflect && cfg->gr_samples <= 4096 && c->bundle_reflections) ? 1 : 0;

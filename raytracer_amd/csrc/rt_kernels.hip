@@ -1011,7 +1011,46 @@ DEVI bool cone_may_hit_sphere(V3 p, V3 a, float sin_t, float cos_t, V3 c, float 
     return !(cos_tb > 0.0f && cos_g < cos_tb - 1e-3f);
 }
 
-DEVI bool cone_may_hit(const DevScene& sc, bool mb, V3 p, V3 lc, float R) {
+// own_gid, N: the primitive the hit lies on and its geometric normal there (as the hit record holds it).  A sphere or a
+// cube is convex, so a ray that starts on its surface and heads outwards cannot meet it again; in the reference's
+// arithmetic: the sample ray starts at p + 0.001 d (raytracer.cpp:549), so with N.d >= m > 0 over the whole cone
+//   sphere.cpp:127-129: tca = (c - o).d = -r N.d - 0.001 +- rounding (a few 1e-6 for coordinates below 1000) < 0: "return false";
+//   cube.cpp:170-215: on the axis of the hit's face the local origin is 1 + e + 0.001 N.d / scale (e: the rounding of the
+//   hit point and of the two rotations, and the 1e-5 by which the face choice of cube.cpp:270-280 may prefer a
+//   neighbouring face at an edge), so the far slab distance is -e / N.d - 0.001 / scale <= 1e-4 as long as
+//   e <= N.d (1e-4 + 0.001 / scale): tmax then never exceeds the test's own threshold of 1e-4 and it reports no hit.
+// Such a primitive is left out of the search below.
+// The same question against a cube itself rather than the sphere around it, in the cube's own frame (cube.cpp:126-168:
+// translate by the location at the ray's time, rotate back, divide by the scale).  A point of a sample ray at distance s
+// from p lies within s sin(theta) of the axis ray p + u a, and s is at most the distance t_max from p to the farthest
+// point of the cube; so a sample ray can only reach the cube - enlarged by eps for what the float test may report
+// outside it - if the axis ray pierces the cube enlarged by eps + t_max sin(theta) on every side.
+DEVI bool cone_may_hit_cube(const float4* __restrict__ rec, bool mb, float time, V3 p, V3 a, float sin_t) {
+    const float4 w0 = rec[0], w1 = rec[1], w4 = rec[4], w5 = rec[5];
+    V3 loc = mk(w0.x, w0.y, w0.z);
+    if (mb) loc = mk(lerp_ref(w0.x, w1.x, time), lerp_ref(w0.y, w1.y, time), lerp_ref(w0.z, w1.z, time));
+    const float inv = fabsf(w1.w);                                       // 1 / scale
+    if (!(inv > 1e-6f && inv < 1e6f)) return true;
+    const V3 pl = rot_inv(p - loc, w4, w5) * inv, al = rot_inv(a, w4, w5);
+    const float dist = __builtin_amdgcn_sqrtf(dot(pl, pl));
+    const float eps = 0.02f + 2e-3f * (dist + 1.0f);
+    const float t_max = dist + 1.7321f * (1.0f + eps) + 0.001f * inv;    // the rays start 0.001 (world units) beyond p
+    const float H = (1.0f + eps + t_max * sin_t) * 1.001f;
+    float tn = 0.0f, tf = INFINITY;                                      // the axis ray: u >= 0
+    const float pv[3] = { pl.x, pl.y, pl.z }, av[3] = { al.x, al.y, al.z };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (fabsf(av[i]) > 1e-6f) {
+            const float rc = __builtin_amdgcn_rcpf(av[i]);
+            const float t0 = (-H - pv[i]) * rc, t1 = (H - pv[i]) * rc;
+            tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+        } else if (fabsf(pv[i]) > H) return false;                       // parallel to this pair of faces and outside them
+    }
+    // (a NaN anywhere makes the comparison false: "may hit")
+    return !(tn > tf * 1.0001f + 1e-4f);
+}
+
+DEVI bool cone_may_hit(const DevScene& sc, bool mb, float time, V3 p, V3 lc, float R, int own_gid, V3 N) {
     const V3 ax = lc - p;
     const float D2 = dot(ax, ax);
     if (!(D2 > 4.0f * R * R) || !(D2 < 1e30f)) return true;             // inside or near the light ball: no useful cone
@@ -1019,17 +1058,29 @@ DEVI bool cone_may_hit(const DevScene& sc, bool mb, V3 p, V3 lc, float R) {
     const V3 a = ax * invD;
     const float sin_t = R * invD * 1.001f + 1e-4f, cos_t = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - sin_t * sin_t));
     const DevPrimSet& S = sc.fileset;
+    // smallest N.d over the cone (N is of unit length up to rounding); NaN compares false everywhere below
+    const float n_a = dot(N, a);
+    const float out_least = n_a * cos_t - __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - n_a * n_a)) * sin_t;
+    const float p_size = fabsf(p.x) + fabsf(p.y) + fabsf(p.z);
     for (int i = 0; i < S.n_spheres; ++i) {
         const float4 w0 = S.spheres[2 * i], w1 = S.spheres[2 * i + 1];
+        if (S.n_planes + S.n_cubes + i == own_gid && out_least > 0.02f && p_size + fabsf(w0.x) + fabsf(w0.y) + fabsf(w0.z) + fabsf(w1.x) + fabsf(w1.y) + fabsf(w1.z) < 1000.0f)
+            continue;                                                    // the hit's own sphere, every sample ray leaving it
         V3 c = mk(w0.x, w0.y, w0.z); float r = fabsf(w0.w);
         if (mb) { const V3 e = mk(w1.x, w1.y, w1.z); const V3 h = (e - c) * 0.5f; c = c + h; r += __builtin_amdgcn_sqrtf(dot(h, h)) * 1.001f; }
         if (cone_may_hit_sphere(p, a, sin_t, cos_t, c, r)) return true;
     }
     for (int i = 0; i < S.n_cubes; ++i) {
         const float4 w0 = S.cubes[6 * i], w1 = S.cubes[6 * i + 1];
+        if (S.n_planes + i == own_gid && out_least > 0.02f && w0.w > 1e-3f) {
+            // e: 1e-5 (face choice) + rounding of the hit point and the rotations, in units of the cube's half edge, doubled
+            const float scale = w0.w;
+            const float e = 1.5e-5f + 2.0f * (2e-7f * (p_size + fabsf(w0.x) + fabsf(w0.y) + fabsf(w0.z) + fabsf(w1.x) + fabsf(w1.y) + fabsf(w1.z)) + 1e-6f * scale) / scale;
+            if (e <= out_least * (1e-4f + 0.001f / scale)) continue;     // the hit's own cube, every sample ray leaving it
+        }
         V3 c = mk(w0.x, w0.y, w0.z); float r = fabsf(w0.w) * 1.7325f;    // half edge x sqrt(3)
         if (mb) { const V3 e = mk(w1.x, w1.y, w1.z); const V3 h = (e - c) * 0.5f; c = c + h; r += __builtin_amdgcn_sqrtf(dot(h, h)) * 1.001f; }
-        if (cone_may_hit_sphere(p, a, sin_t, cos_t, c, r)) return true;
+        if (cone_may_hit_sphere(p, a, sin_t, cos_t, c, r) && cone_may_hit_cube(S.cubes + 6 * i, mb, time, p, a, sin_t)) return true;
     }
     for (int i = 0; i < S.n_planes; ++i) {
         const float4 w0 = S.planes[3 * i], w1 = S.planes[3 * i + 1];
@@ -1185,7 +1236,8 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                     const float4 lt = (L == 1) ? light0 : sc.lights[l];
                     if (!faces_light(a, b, lt)) out[item] = 0;
                     else if (!SUB && MODE != 0 && cull &&
-                             !cone_may_hit(sc, f.motion_blur != 0, mk(a.x, a.y, a.z), mk(lt.x, lt.y, lt.z), f.light_radius)) out[item] = SS;
+                             !cone_may_hit(sc, f.motion_blur != 0, a.w, mk(a.x, a.y, a.z), mk(lt.x, lt.y, lt.z), f.light_radius,
+                                           f.cull_own ? (f2i(b.w) & 0x7fffffff) : -1, mk(b.x, b.y, b.z))) out[item] = SS;
                     else queue = true;
                 }
             }

@@ -98,6 +98,7 @@ struct DevFrame {
     int skip_unlit;                // shadow rays of (hit, light) pairs whose N.L is clearly negative are not traced
     int replicate;                 // soft shadows: the first reflection of a path is traced gr_samples times (see k_extend)
     int cull_cones;                // soft shadows of tiny scenes: (hit, light) pairs whose whole cone of sample rays misses everything are not traced
+    int cull_own;                  // ... and a convex primitive (sphere, cube) is not searched for the sample rays that leave its own surface outwards
     int bundle;                    // ... as ONE traced ray whose node has gr_samples copies (replicate, no glossy perturbation)
     int count_stats;               // kernels add their ray counts to DevWork::stats (one atomic per workgroup and counter)
     // sharding

@@ -12,7 +12,7 @@ import pytest
 
 import cases
 import oracle
-from raytracer_amd import api
+from raytracer_amd import api, scenegen as sg
 
 pytestmark = pytest.mark.gpu
 
@@ -156,3 +156,61 @@ def test_untraced_soft_shadow_cones_change_no_pixel(scene, flags, textures_dir):
         assert (on.shadow_rays_ref, on.reflection_rays, on.nodes_shaded) == (off.shadow_rays_ref, off.reflection_rays, off.nodes_shaded)
         assert on.shadow_rays <= off.shadow_rays
     ls.close()
+
+
+def _small_random_scene(rng, res):
+    """At most eight primitives (the cone rule's limit): rotated, scaled and moving cubes standing in or near a ground
+    plane, spheres, sometimes a tilted polygon; one or two lights."""
+    cams = [sg.camera((rng.uniform(-2, 2), rng.uniform(-11, -7), rng.uniform(0.8, 4)), (rng.uniform(-0.2, 0.2), 1.0, rng.uniform(-0.3, 0.05)), res=res)]
+    lights = [sg.light((rng.uniform(-6, 6), rng.uniform(-5, 4), rng.uniform(2.5, 9)), rng.uniform(300, 1500)) for _ in range(rng.integers(1, 3))]
+
+    def mat():
+        return sg.material(rng.uniform(0, 1, 3), rng.uniform(0, 0.3, 3) * rng.integers(0, 2), float(rng.choice([5.0, 64.0, 200.0])),
+                           float(rng.choice([0.0, 0.0, 0.6])), float(rng.choice([1.0, 1.3, 1.5])))
+
+    def place():
+        return (rng.uniform(-3.5, 3.5), rng.uniform(-3, 6), rng.uniform(-0.3, 2.5))
+    cubes = []
+    for _ in range(rng.integers(1, 4)):
+        c = place()
+        end = (c[0] + rng.uniform(-1, 1), c[1] + rng.uniform(-1, 1), c[2] + rng.uniform(0, 3)) if rng.uniform() < 0.4 else None
+        cubes.append(sg.cube(c, rng.uniform(0.2, 2.0), mat(), rotation=rng.uniform(0, 6.28, 3) * rng.integers(0, 2, 3), end=end))
+    spheres = []
+    for _ in range(rng.integers(0, 3)):
+        c = place()
+        end = (c[0] + rng.uniform(-1, 1), c[1], c[2] + rng.uniform(0, 2)) if rng.uniform() < 0.3 else None
+        spheres.append(sg.sphere(c, rng.uniform(0.2, 1.4), mat(), end=end))
+    planes = [sg.ground(float(rng.uniform(8, 24)), float(rng.uniform(-0.3, 0.2)), mat())]
+    if rng.uniform() < 0.4:
+        n = int(rng.integers(3, 6)); c = np.array([rng.uniform(-3, 3), rng.uniform(0, 6), rng.uniform(0.5, 3)])
+        a = rng.normal(size=3); a /= np.linalg.norm(a); b = np.cross(a, rng.normal(size=3)); b /= np.linalg.norm(b)
+        planes.append(sg.plane([c + 1.5 * (np.cos(2 * np.pi * k / n) * a + np.sin(2 * np.pi * k / n) * b) for k in range(n)], mat()))
+    return sg.scene_text(cams, lights, spheres, cubes, planes)
+
+
+def test_untraced_soft_shadow_cones_change_no_pixel_on_random_small_scenes(textures_dir):
+    """The same property on 40 random scenes of at most eight primitives - cubes of any rotation and size, some moving, next
+    to and inside a ground plane, spheres, polygons - with soft shadows, recursion and motion blur drawn at random: what the
+    cone rule leaves untraced (a primitive's own surface left outwards, cubes tested in their own frame) changes no pixel."""
+    rng = np.random.default_rng(20260)
+    traced_on = traced_off = 0
+    for k in range(40):
+        text = _small_random_scene(rng, (160, 90))
+        flags = ["-ss", "-sss", str(int(rng.choice([4, 16])))]
+        if rng.uniform() < 0.5:
+            flags += ["-r", "-rd", "2"] + (["-grs", "2"] if rng.uniform() < 0.5 else [])
+        if rng.uniform() < 0.4:
+            flags += ["-m", "-mbs", "2"]
+        cfg, _ = api.parse_args(flags); cfg.seed = 100 + k
+        ls = api.LoadedScene(text, cfg, textures_dir)
+        fast = int(k % 2)
+        got = []
+        for cull in (1, 0):
+            r = api.Renderer(0); r.set_option("cull_cones", cull); r.set_option("fast_samples", fast)
+            r.upload(ls, with_bvh=True)
+            got.append(r.render(cfg)); r.close()
+        ls.close()
+        assert np.array_equal(got[0][0], got[1][0]), f"case {k} flags {flags} fast_samples {fast}: {(got[0][0] != got[1][0]).any(axis=2).sum()} pixels differ"
+        assert got[0][1].shadow_rays_ref == got[1][1].shadow_rays_ref
+        traced_on += got[0][1].shadow_rays; traced_off += got[1][1].shadow_rays
+    assert traced_on < 0.7 * traced_off
