@@ -430,10 +430,12 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
         to_host = {}
         for kind, buf in (("page_locked", api.image_buffer(r.out_bytes())), ("pageable", np.zeros(r.out_bytes(), dtype=np.uint8))):
             r.render(cfg, out=buf, want_stats=False)
-            t_h = time.perf_counter()
+            each = []
             for _ in range(n_lat):
+                t_h = time.perf_counter()
                 r.render(cfg, out=buf, want_stats=False)
-            to_host[kind] = (time.perf_counter() - t_h) * 1000.0 / n_lat
+                each.append((time.perf_counter() - t_h) * 1000.0)
+            to_host[kind] = sorted(each)[len(each) // 2]             # median: a frame to the host is a host-timed quantity
         del buf
     # every context records a frame graph on its second frame with the same output buffer; a pipeline alternates
     # between two blocks, so it needs four frames before both graphs exist
