@@ -204,6 +204,13 @@ void* rt_get_stream(rt_ctx* ctx);
  * "cull_cones" = 0/1 (soft shadows, scenes of at most 8 primitives): whether the sample rays of a (hit, light) pair are left
  * untraced when the whole cone from the hit to the light ball provably reaches no primitive (default 1; every sample is then
  * unblocked whatever the random numbers, so frames are identical; rt_stats.shadow_rays counts traced rays).
+ * "cull_own" = 0/1 (with cull_cones): whether a sphere or cube is left out of that search for sample rays that all leave
+ * its own surface outwards (a convex primitive cannot be met again; default 1, frames identical).
+ * "hierarchy_order" = 0/1 (before rt_upload_scene): whether the records of groups with a second-level hierarchy are
+ * stored in hierarchy order, a run's primitives side by side (default 1; the reference's testing order, which decides
+ * exact ties, is kept per entry).  "sort_rays" = 0/1 and "sort_rays_min_prims" = N: whether the secondary rays of scenes
+ * with second-level hierarchies and at least N primitives (default 2 000 000) are sorted by origin cell and direction
+ * before they are traced (default 1; only the order of tracing changes; such frames are not recorded into graphs).
  * "count_rays" = 0/1: whether rt_render_device with a statistics pointer counts rays (default 1) or only times the
  * stages, with the kernels plain frames use (the ray counts then read 0).
  * "max_grid" (all kernels) or "grid_primary" / "grid_secondary" / "grid_shadow" / "grid_shade" = workgroups per launch,
