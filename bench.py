@@ -129,6 +129,20 @@ def cpu_baseline(workload: dict) -> dict:
                    port_value=rays / max(ost.seconds, 1e-9))
     else:
         out.update(kind="port", value=rays / max(ost.seconds, 1e-9), seconds=ost.seconds)
+    # the same sample without the BVH (-u, raytracer.cpp:202-256), the reference's other code path
+    if "-u" not in sample_flags:
+        try:
+            u_flags = sample_flags + ["-u"]
+            _, ust = oracle.render(text, u_flags, textures)
+            un = {"flags": " ".join(u_flags), "rays": ust.total_rays(), "cores": 1}
+            if ref_runner.have_ref():
+                _, usecs, _ = ref_runner.run_ref(text, u_flags, {p.name: p for p in cases.TEXTURES.glob("*.ppm")})
+                un.update(kind="reference", value=ust.total_rays() / max(usecs, 1e-9), seconds=usecs)
+            else:
+                un.update(kind="port", value=ust.total_rays() / max(ust.seconds, 1e-9), seconds=ust.seconds)
+            out["unaccelerated"] = un
+        except Exception as e:
+            out["unaccelerated"] = {"error": repr(e)}
     try:
         out.update(port_all_cores(text, sample_flags, w, h, textures))
     except Exception as e:                      # a reported extra, never a reason to lose the line
