@@ -946,8 +946,13 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
                 w.n_a[node] = make_float4(h.p.x, h.p.y, h.p.z, r.time);
                 w.n_b[node] = make_float4(h.n.x, h.n.y, h.n.z, i2f(h.gid | (copies > 1 ? (int)0x80000000 : 0)));
                 if (f.textures) w.n_uv[node] = make_float2(h.u, h.v);
-                const int packed = f.bundle ? (n_reflect | (copies << 13) | (1 << 29) | (refract ? (1 << 30) : 0)) : (n_reflect | (refract ? (1 << 30) : 0));
-                w.n_c[node] = make_float4(i2f(n_children ? first_link : -1), weight, i2f((int)path), i2f(packed));
+                // the third word - children, refraction weight, path id - has readers only where a hit can have children
+                // (k_shade) or draws shadow samples (k_shadow, soft shadows): hits of the last level of a frame with hard
+                // shadows, i.e. every hit of a frame without recursion, do not write it
+                if (spawn || f.soft_shadows) {
+                    const int packed = f.bundle ? (n_reflect | (copies << 13) | (1 << 29) | (refract ? (1 << 30) : 0)) : (n_reflect | (refract ? (1 << 30) : 0));
+                    w.n_c[node] = make_float4(i2f(n_children ? first_link : -1), weight, i2f((int)path), i2f(packed));
+                }
             }
             if (PRIMARY) w.n_pix[node] = slot;
             const float EPS = 1e-4f;
@@ -1356,7 +1361,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, Dev
         if (k >= __builtin_amdgcn_readfirstlane(s_cnt[seg])) continue;
         const int node = w.node_off[level] + seg * w.node_rcap[level] + k;
         const int slot0 = w.slot_off[level] + (node - w.node_off[level]) * mul;      // slot of the node's copy 0
-        float4 a = w.n_a[node], b = w.n_b[node], c = w.n_c[node];
+        const bool has_children = level < f.max_depth;
+        float4 a = w.n_a[node], b = w.n_b[node];
+        const float4 c = (has_children || f.soft_shadows) ? w.n_c[node] : make_float4(i2f(-1), 0.0f, 0.0f, 0.0f);   // (not written otherwise, see k_extend)
         const int gid = f2i(b.w) & 0x7fffffff;
         float4 m0 = sc.mats[3 * gid], m1 = sc.mats[3 * gid + 1], m2 = sc.mats[3 * gid + 2];
         V3 p = mk(a.x, a.y, a.z), N = mk(b.x, b.y, b.z);
@@ -1377,7 +1384,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, Dev
         }
         // what the node's children contribute (raytracer.cpp:369-503): the same structure for every copy
         const int first = f2i(c.x), packed = f2i(c.w);
-        const bool has_children = level < f.max_depth;
         const bool bundle = (packed >> 29) & 1;
         const int n_reflect = bundle ? (packed & 0x1fff) : (packed & 0x1fffffff);
         const int copies = bundle ? ((packed >> 13) & 0xffff) : 1;
