@@ -217,6 +217,7 @@ struct rt_ctx {
     // 0 = chosen per launch (see enqueue_frame)
     int grid_primary = 0, grid_secondary = 0, grid_shadow = 0, grid_shade = 0;
     bool cull_cones = true;                  // see k_shadow: soft-shadow cones that miss every primitive are not traced
+    bool fuse_simple = true;                 // frames without recursion and with hard shadows: trace, shadow and shade in one kernel
     bool cull_own = true;                    // ... where a sphere or cube is left out for the rays that leave its own surface outwards
     bool bundle_reflections = true;          // ... as one traced ray with gr_samples hit records (off: gr_samples traced rays)
     bool replicate_reflections = true;       // soft shadows: first reflections traced gr_samples times, each with its own shadow samples
@@ -393,6 +394,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "count_rays") == 0) { c->count_rays = value != 0; return RT_OK; }
     if (std::strcmp(name, "fast_samples") == 0) { c->fast_samples = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "cull_cones") == 0) { c->cull_cones = value != 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "fuse_simple") == 0) { c->fuse_simple = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "cull_own") == 0) { c->cull_own = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "bundle_reflections") == 0) { c->bundle_reflections = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "replicate_reflections") == 0) { c->replicate_reflections = value != 0; c->drop_graphs(); return RT_OK; }
@@ -1258,6 +1260,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     const unsigned long long n_batches = (unsigned long long)((n_slots + B - 1) / B) * (unsigned long long)S;
     if (n_batches > 64) tm->on = false;
     tm->reserve((size_t)n_batches * (size_t)(2 * D + 4) * 2 + 2);
+    const bool fused = c->fuse_simple && D == 0 && !cfg->soft_shadows;
     const bool split = L > 0 && D >= 1 && plan.fanout;                 // shadow rays in two launches: level 0, then the rest
     const bool overlap = split && c->overlap && !tm->on;         // stage times are only meaningful on one stream
     for (long long begin = 0; begin < n_slots; begin += B) {
@@ -1284,6 +1287,14 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         const int grid0 = std::max(1, std::min(g_primary, chunks0_batch));
         for (int smp = 0; smp < S; ++smp) {
             f.sample = smp;
+            if (fused) {
+                // no recursion, hard shadows: the whole batch is one launch (k_primary_shaded)
+                tm->begin(ST_EXTEND_PRIMARY);
+                rt_launch_primary_shaded(s, c->scene, f, w, grid0);
+                tm->end();
+                ++batches;
+                continue;
+            }
             if (batches > 0) RT_HIP(c, hipMemsetAsync(w.ctr, 0, RT_C_TOTAL * sizeof(int), s));   // counters of the batch
             if (!grouped) RT_HIP(c, hipMemsetAsync(w.shadow, 0, plan.cap_shadow * sizeof(float), s));
             for (int level = 0; level <= D; ++level) {

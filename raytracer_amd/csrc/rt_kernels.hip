@@ -1495,6 +1495,105 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, Dev
     if (f.count_stats) block_stat_add(&w.stats[RT_S_NODES], n_shaded, s_tmp);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Frames without recursion and with hard shadows - the reference's default render and its multi-sample flag sets
+// without -r / -ss - in one kernel: a lane generates its primary ray, traces it, sends one shadow ray per light from
+// the hit (raytracer.cpp:509-530), shades (raytracer.cpp:262-347) and adds the colour to its pixel.  No hit record,
+// shadow count or pixel slot goes through memory and the frame is one launch instead of three; the arithmetic is that
+// of k_extend, k_shadow (hard shadows) and k_shade for a hit without children, statement for statement.
+// ---------------------------------------------------------------------------------------------------------
+template <int SUB, bool LDSP, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAVES) void k_primary_shaded(DevScene sc_arg, DevFrame f, DevWork w) {
+    extern __shared__ float4 s_mem[];
+    DevScene sc = sc_arg;
+    float4* s_nodes = s_mem;
+    const int4* s_leaves = SUB ? sc.leaves : (const int4*)(s_mem + 2 * sc.n_nodes);
+    int* s_stack = (int*)(s_mem + 2 * sc.n_nodes) + threadIdx.x;                      // [depth][thread], only with SUB
+    __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
+    const int n_chunks = (f.pix_count + RT_BLOCK - 1) / RT_BLOCK;
+    if ((int)blockIdx.x >= n_chunks) return;
+    if (f.use_bvh) stage_bvh(sc, s_nodes, (int4*)(s_mem + 2 * sc.n_nodes), !SUB);
+    if (LDSP) stage_prims(sc, s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves);
+    const int L = sc.n_lights;
+    const V3 cam = mk(f.cam_loc[0], f.cam_loc[1], f.cam_loc[2]);
+    unsigned n_primary = 0, n_shadow = 0, n_hits = 0;                  // per thread: one ray per round
+    for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
+        const int i = g * RT_BLOCK + (int)threadIdx.x;
+        bool active = i < f.pix_count;
+        Ray r; uint32_t path = 0; int slot = 0;
+        r.o = mk(0, 0, 0); r.d = mk(0, 0, 1); r.time = 0.0f;
+        if (active) active = generate_primary(f, i, r, path, slot);
+        Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
+        const bool hit = active && trace<false, SUB, false, false>(sc, f, s_nodes, s_leaves, s_stack, r, false, best);
+        if (STATS) { n_primary += active ? 1u : 0u; n_hits += hit ? 1u : 0u; }
+        if (!hit) continue;
+        HitOut h;
+        full_hit<SUB>(sc, f, r, best, h);
+        const V3 p = h.p, N = h.n;
+        const float4 m0 = sc.mats[3 * h.gid], m1 = sc.mats[3 * h.gid + 1], m2 = sc.mats[3 * h.gid + 2];
+        const float ka = 0.25f, shiny = m0.w;
+        V3 mat = mk(m0.x, m0.y, m0.z);
+        const int tex = f2i(m2.y);
+        if (f.textures && tex >= 0) {                                    // raytracer.cpp:271-297
+            const int4 td = sc.tex_desc[tex];
+            float u = fmodf(h.u, 1.0f); if (h.u < 0) u += 1.0f;
+            float v = fmodf(h.v, 1.0f); if (h.v < 0) v += 1.0f;
+            int xi = (int)(u * (float)(td.x - 1)); if (td.x - 1 < xi) xi = td.x - 1;
+            int yi = (int)((1.0f - v) * (float)(td.y - 1)); if (td.y - 1 < yi) yi = td.y - 1;
+            if (xi < 0) xi = 0;
+            if (yi < 0) yi = 0;
+            const float4 tx = sc.texels[td.z + yi * td.x + xi];
+            mat = mk(tx.x, tx.y, tx.z);
+        }
+        const V3 V = normalise(cam - p);
+        V3 col = mk(ka * mat.x, ka * mat.y, ka * mat.z);
+        for (int l = 0; l < L; ++l) {
+            const float4 lt = sc.lights[l];
+            // the shadow ray (k_shadow, hard shadows): not traced where the surface clearly faces away from the light
+            bool unblocked = false;
+            {
+                const V3 Lr = mk(lt.x - p.x, lt.y - p.y, lt.z - p.z);
+                const float d = dot(N, Lr);
+                const bool faces = !f.skip_unlit || !(d < 0.0f && d * d > 1e-6f * dot(N, N) * dot(Lr, Lr));
+                if (faces) {
+                    Ray sr; sr.time = r.time;
+                    sr.d = normalise(Lr);
+                    sr.o = p + N * 1e-2f;                                // raytracer.cpp:515: unflipped geometric normal
+                    Best sb; sb.t = 0.0f; sb.cls = 0; sb.idx = 0; sb.fileset = 0;
+                    if (STATS) ++n_shadow;
+                    unblocked = !trace<true, SUB>(sc, f, s_nodes, s_leaves, s_stack, sr, false, sb);
+                }
+            }
+            V3 Lv = mk(lt.x - p.x, lt.y - p.y, lt.z - p.z);
+            const float L_len = len_ref(Lv);
+            Lv = normalise(Lv);
+            const float irr = (float)((double)lt.w / ((double)1.0f + (double)L_len * (double)L_len));   // raytracer.cpp:320
+            const V3 H = normalise(Lv + V);
+            const float N_L = smax(0.0f, dot(N, Lv));
+            const float N_H = smax(0.0f, dot(N, H));
+            const float pw = powf_ref(N_H, shiny);
+            const V3 spec = mk(0.5f * m1.x * pw * irr, 0.5f * m1.y * pw * irr, 0.5f * m1.z * pw * irr);
+            const float shadow = unblocked ? 1.0f : 0.0f;
+            col.x += shadow * mat.x * N_L * irr + spec.x;
+            col.y += shadow * mat.y * N_L * irr + spec.y;
+            col.z += shadow * mat.z * N_L * irr + spec.z;
+        }
+        col.x = smin(1.0f, smax(col.x, 0.0f));                           // raytracer.cpp:342-344
+        col.y = smin(1.0f, smax(col.y, 0.0f));
+        col.z = smin(1.0f, smax(col.z, 0.0f));
+        if (f.direct_out) store_pixel(f, f.direct_out, f.direct_tile_major, slot, col.x * 1.0f, col.y * 1.0f, col.z * 1.0f);
+        else {
+            const float4 acc = w.accum[slot];
+            w.accum[slot] = make_float4(acc.x + col.x, acc.y + col.y, acc.z + col.z, 0.0f);
+        }
+    }
+    if (!STATS) return;
+    block_stat_add(&w.stats[RT_S_PRIMARY], (unsigned long long)n_primary, s_tmp);
+    block_stat_add(&w.stats[RT_S_SHADOW], (unsigned long long)n_shadow, s_tmp);
+    block_stat_add(&w.stats[RT_S_SHADOW_REF], (unsigned long long)n_hits * (unsigned long long)L, s_tmp);
+    block_stat_add(&w.stats[RT_S_NODES], (unsigned long long)n_hits, s_tmp);
+}
+
 // Secondary rays of crowded scenes, re-coalesced before they are traced.  The rays a level queues sit in the order their
 // parents were traced; neighbouring lanes then start at unrelated points and walk unrelated parts of the second-level
 // hierarchies (a wavefront of such rays costs two to three times one of neighbouring rays).  This kernel gives every
@@ -1615,6 +1714,20 @@ void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, cons
         else RT_EXTEND_LAUNCH(false, 0, false);
     }
 #undef RT_EXTEND_LAUNCH
+}
+
+void rt_launch_primary_shaded(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid) {
+    const size_t lds = bvh_lds_bytes(sc, f, !f.use_bvh);
+    const bool sub = sc.sub_nodes != nullptr;
+    const bool ldsp = !sub && sc.lds_prims > 1;
+#define RT_FUSED_LAUNCH(SUB, LDSP) \
+    do { if (f.count_stats) hipLaunchKernelGGL((k_primary_shaded<SUB, LDSP, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w); \
+         else hipLaunchKernelGGL((k_primary_shaded<SUB, LDSP, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w); } while (0)
+    if (sub && sc.sub_stride == 8) RT_FUSED_LAUNCH(2, false);
+    else if (sub) RT_FUSED_LAUNCH(1, false);
+    else if (ldsp) RT_FUSED_LAUNCH(0, true);
+    else RT_FUSED_LAUNCH(0, false);
+#undef RT_FUSED_LAUNCH
 }
 
 void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid) {

@@ -186,6 +186,7 @@ static inline int rt_sub_stack_entries(int depth) { return 3 * ((depth + 1) / 2)
 
 // kernel launchers (rt_kernels.hip)
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);
+void rt_launch_primary_shaded(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid);
 void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid);
 void rt_launch_sort_keys(hipStream_t s, const DevScene& sc, const DevWork& w, int level, unsigned* keys, unsigned* slots);
 void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);

@@ -264,6 +264,26 @@ def test_untraced_shadow_rays_of_unlit_sides_change_no_pixel(scene, flags, textu
             assert off.shadow_rays == ost.shadow
 
 
+@pytest.mark.parametrize("scene,flags", [("ref", []), ("ref", ["-u"]), ("glass_tex", ["-t"]), ("glass_tex", ["-t", "-u"]), ("bvh5", []), ("rand300m", []),
+                                         ("ref", ["-aa", "-aas", "2", "-dof", "-dofs", "2", "-m", "-mbs", "2"]), ("glass", ["-m", "-mbs", "3", "-gr", "-grs", "4"])])
+def test_one_kernel_frames_equal_the_three_stage_pipeline(scene, flags, textures_dir):
+    """Frames without recursion and with hard shadows are rendered by one kernel (generate, trace, shadow rays, shade).
+    Its images, ray counts and shaded-hit counts must equal those of the extend / shadow / shade pipeline with the
+    option off - unsharded, as one of three shards, and in several batches."""
+    cfg, _ = api.parse_args(flags + ["-rd", "0"]); cfg.seed = 5
+    ls = api.LoadedScene(cases.SCENES[scene](), cfg, textures_dir)
+    for world, workspace in ((1, 0), (3, 0), (1, 6 << 20)):
+        got = []
+        for fuse in (1, 0):
+            r = api.Renderer(0, workspace); r.set_option("fuse_simple", fuse)
+            r.upload(ls, with_bvh=bool(cfg.bvh)); r.set_shard(world - 1, world)
+            img, st = r.render(cfg)
+            got.append((img, (st.primary_rays, st.shadow_rays, st.shadow_rays_ref, st.nodes_shaded, st.reflection_rays), st.launches_shadow)); r.close()
+        assert got[0][0].max() > 0 and np.array_equal(got[0][0], got[1][0]), f"world {world}: {(got[0][0] != got[1][0]).any(axis=-1).sum()} pixels differ"
+        assert got[0][1] == got[1][1] and got[0][2] == 0 and got[1][2] > 0
+    ls.close()
+
+
 # ---- large scenes: the second-level hierarchy ----------------------------------------------------------------
 
 @pytest.mark.parametrize("n,res,flags", [(20000, (960, 540), []), (20000, (960, 540), ["-u"]),
