@@ -194,6 +194,11 @@ def roofline(st, workload: str, small_scene: bool) -> dict:
         "k_shadow": dict(units=st.shadow_rays, bytes_per_unit=BYTES_PER_SHADOW_RAY, ms=st.ms_shadow, launches=st.launches_shadow),
         "k_shade": dict(units=st.nodes_shaded, bytes_per_unit=BYTES_PER_SHADED_HIT, ms=st.ms_shade, launches=st.launches_shade),
     }
+    if st.launches_shadow == 0 and st.launches_shade == 0 and st.launches_extend_primary > 0:
+        # frames without recursion and with hard shadows run as one kernel: primary rays, their shadow rays and the shading
+        units = st.primary_rays + st.shadow_rays
+        total = st.primary_rays * BYTES_PER_EXTEND_RAY + st.shadow_rays * BYTES_PER_SHADOW_RAY + st.nodes_shaded * BYTES_PER_SHADED_HIT
+        kernels = {"k_primary_shaded": dict(units=units, bytes_per_unit=total / max(1, units), ms=st.ms_extend_primary, launches=st.launches_extend_primary)}
     ctr = load_counters(workload)
     for name, k in kernels.items():
         n = max(1, k["launches"])
@@ -245,6 +250,7 @@ def roofline(st, workload: str, small_scene: bool) -> dict:
                         "launch during which the vector ALUs execute (SQ_ACTIVE_INST_VALU), which prices slow instructions at what they cost")
     elif not small_scene and d.get("hbm_GBps"):
         out.update(bound="hbm", achieved=d["hbm_GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=d["hbm_GBps"] / HBM_PEAK_GBS,
+                   valu_busy_frac=d.get("valu_busy_frac"), valu_issue_frac=d.get("valu_issue_frac"),
                    note="achieved = HBM bytes of the launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, committed counter pass) / launch duration "
                         "measured live.  The walk of the second-level hierarchies is bound by the latency of dependent node and "
                         "primitive fetches (L2 / Infinity Cache), not by streaming bandwidth; l2_hit_rate is from the same passes")

@@ -12,6 +12,8 @@ def find(pattern):
 
 
 def short(name):
+    if "k_primary_shaded" in name:
+        return "k_primary_shaded"
     for k in ("k_extend<true", "k_extend<false", "k_shadow", "k_shade", "k_finalize", "k_assemble"):
         if k in name:
             return k + (">" if k.startswith("k_extend") else "")
