@@ -211,6 +211,9 @@ void* rt_get_stream(rt_ctx* ctx);
  * exact ties, is kept per entry).  "sort_rays" = 0/1 and "sort_rays_min_prims" = N: whether the secondary rays of scenes
  * with second-level hierarchies and at least N primitives (default 2 000 000) are sorted by origin cell and direction
  * before they are traced (default 1; only the order of tracing changes; such frames are not recorded into graphs).
+ * "fuse_simple" = 0/1: whether frames without recursion and with hard shadows run as one kernel (trace, shadow rays,
+ * shading and the pixel sum in the lane of the primary ray) instead of the extend / shadow / shade sequence; default 1,
+ * frames and statistics identical.
  * "count_rays" = 0/1: whether rt_render_device with a statistics pointer counts rays (default 1) or only times the
  * stages, with the kernels plain frames use (the ray counts then read 0).
  * "max_grid" (all kernels) or "grid_primary" / "grid_secondary" / "grid_shadow" / "grid_shade" = workgroups per launch,
