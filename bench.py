@@ -318,10 +318,12 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
         costs fewer workgroup start-ups."""
         rr.set_option("overlap", 0 if (in_flight and (P >= 3 or world > 1)) else 1)
         rr.set_option("grid_shadow", 1536 if (in_flight and P >= 3 and soft_small) else 0)
+        rr.set_option("grid_primary", 1024 if (in_flight and P >= 3 and one_kernel_small) else 0)
         for kv in filter(None, os.environ.get("RT_BENCH_OPTS", "").split(",")):      # development: name=value library options
             rr.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
     soft_small = bool(cfg.soft_shadows) and wl["scene"] != "random"
+    one_kernel_small = (not cfg.soft_shadows) and cfg.reflect_refract_depth <= 0 and wl["scene"] != "random"     # frames rendered by one kernel
 
     def new_renderer():
         rr = api.Renderer(local, workspace_bytes=16 << 30)
