@@ -285,6 +285,9 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
 
     wl = WORKLOADS[name]
     W, H = wl["res"]
+    # multi: the frame goes through the process group (gather to rank 0, re-ordering).  True for one rank too in the
+    # RCCL rehearsal on a one-GPU machine, which runs the communicator calls of the N > 1 path with a group of one.
+    multi = world > 1 or args.rehearse_rccl
     # Rank 0 parses the scene and builds the BVH on its host; flags and the flat scene/BVH arrays are broadcast once
     # per frame set (over RCCL with the nccl backend), every rank uploads its copy.
     on_dev = dev if (world > 1 and args.backend != "gloo") else None
@@ -308,7 +311,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     # of many samples per pixel, which keep the GPU busy on their own.
     spp = cfg.samples_per_pixel()
     P = max(1, frames_in_flight) if (spp <= 64 and W * H <= 1920 * 1080) else 1
-    if world > 1:
+    if multi:
         P = min(P, 3)                                 # the communicator's stream takes the fourth hardware queue
 
     def set_mode(rr, in_flight: bool):
@@ -316,7 +319,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
         workgroup per chunk or two in the soft-shadow launches so that no workgroup holds the frame up).  Frames in
         flight fill each other's gaps instead: no forked streams (hardware queues are few) and the smaller grid, which
         costs fewer workgroup start-ups."""
-        rr.set_option("overlap", 0 if (in_flight and (P >= 3 or world > 1)) else 1)
+        rr.set_option("overlap", 0 if (in_flight and (P >= 3 or multi)) else 1)
         rr.set_option("grid_shadow", 1536 if (in_flight and P >= 3 and soft_small) else 0)
         rr.set_option("grid_primary", 1024 if (in_flight and P >= 3 and one_kernel_small) else 0)
         for kv in filter(None, os.environ.get("RT_BENCH_OPTS", "").split(",")):      # development: name=value library options
@@ -357,7 +360,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     # gather runs on the communicator's stream and rank 0 re-orders it, both beside the kernels of frame k + 1.
     # Buffers are reused every other frame behind events; the timed region ends with a device-wide synchronisation,
     # so every frame's image has reached rank 0 inside it.
-    pipelined = world > 1 and not staged
+    pipelined = multi and not staged
     # With several pipelines taking turns, rank 0 re-orders each frame on that frame's own render stream (no fifth stream)
     inline = P >= 2
     asm_stream = torch.cuda.Stream(dev) if (pipelined and rank == 0 and not inline) else None
@@ -430,7 +433,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     rays_local = torch.tensor([st.primary_rays, st.shadow_rays, st.reflection_rays, st.refraction_rays,
                                st.shadow_rays_ref + st.reflection_rays_ref + st.refraction_rays_ref, st.nodes_shaded],
                               dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         rays_local = rays_local.cpu() if staged else rays_local
         dist.all_reduce(rays_local)
     tot = [int(x) for x in rays_local.tolist()]
@@ -471,19 +474,19 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     torch.cuda.synchronize(dev)
     for _ in range(warmup):
         step()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     t_enq = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staged else dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -491,7 +494,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     if rank == 0:
         # rank-0 sanity: the frame is not black and (N=1) is the row-major image itself
         last = (frame_no[0] - 1) % P
-        final = ((pipes[last].image if pipelined else image) if world > 1 else ctxs[last][2]).cpu().numpy()
+        final = ((pipes[last].image if pipelined else image) if multi else ctxs[last][2]).cpu().numpy()
         lit = float((final.reshape(-1, 3).sum(axis=1) > 0).mean())
         res = {"workload": describe(name), "value": rays_total / (elapsed / steps), "ms_per_step": 1000.0 * elapsed / steps,
                "steps": steps, "warmup": warmup, "graph_recording_frames": prime_steps, "spp": spp, "frames_in_flight": P, "frame_ms_alone": frame_latency_ms,
@@ -529,6 +532,8 @@ def main():
                     help="rehearsal on a one-GPU machine: every rank uses GPU 0 (use with --backend gloo)")
     ap.add_argument("--no-variants", action="store_true",
                     help="profiling runs: no frames with other library options (the counts of untraced shadow rays are then not reported)")
+    ap.add_argument("--rehearse-rccl", action="store_true",
+                    help="one-GPU machine: one rank in an RCCL process group of one, frames through the N > 1 path (pipelined gather, re-ordering)")
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks, initialise the process group, reduce one number, print it and stop (needs no GPU)")
     args = ap.parse_args()
@@ -567,6 +572,9 @@ def main():
             dist.destroy_process_group()
         return
     rank, world, local = rdist.init_process_group(args.backend)
+    if args.rehearse_rccl and world == 1 and torch.cuda.is_available():
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the render path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
@@ -618,7 +626,7 @@ def main():
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
