@@ -496,6 +496,8 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
         last = (frame_no[0] - 1) % P
         final = ((pipes[last].image if pipelined else image) if multi else ctxs[last][2]).cpu().numpy()
         lit = float((final.reshape(-1, 3).sum(axis=1) > 0).mean())
+        import zlib
+        crc = zlib.crc32(final.tobytes())                # of the row-major RGB bytes of the last timed frame
         res = {"workload": describe(name), "value": rays_total / (elapsed / steps), "ms_per_step": 1000.0 * elapsed / steps,
                "steps": steps, "warmup": warmup, "graph_recording_frames": prime_steps, "spp": spp, "frames_in_flight": P, "frame_ms_alone": frame_latency_ms,
                "frame_ms_to_host": to_host, "host_enqueue_ms_per_step": 1000.0 * t_enq / steps, "upload_seconds": upload_s,
@@ -505,7 +507,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
                                       (shadow_all - shadow_no_cone) if (world == 1 and shadow_all is not None) else None,
                                   "shadow_not_traced_because_no_sample_ray_of_the_pair_can_reach_a_primitive":
                                       (shadow_no_cone - st.shadow_rays) if (world == 1 and shadow_no_cone is not None) else None},
-               "lit_fraction": lit, "stats": st}
+               "lit_fraction": lit, "image_crc32": crc, "stats": st}
     torch.cuda.synchronize(dev)
     torch.cuda.set_stream(torch.cuda.default_stream(dev))      # the contexts' streams die with them
     for rr, _, _ in ctxs:
@@ -609,7 +611,7 @@ def main():
                                                "samples, as the reference's identical rays do; one traced ray per bundle); deeper reflections once",
                        "value_counts": "traced rays only: shadow rays whose outcome is certain without tracing (surface facing away from the light; "
                                        "no sample ray of the pair can reach a primitive) and the identical copies of a reflection ray are not counted",
-                       "rays_per_frame": head["rays_per_frame"], "lit_fraction": head["lit_fraction"]},
+                       "rays_per_frame": head["rays_per_frame"], "lit_fraction": head["lit_fraction"], "image_crc32": head["image_crc32"]},
             "roofline": roofline(st, args.workload, wl["scene"] != "random"),
         }
         ceiling = copy_ceiling_GBps(torch, dev)

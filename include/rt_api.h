@@ -270,7 +270,8 @@ int rt_render_device_noalloc(rt_ctx* ctx, const rt_config* cfg, void* rgb_out_de
 uint64_t rt_noalloc_capacity(void);
 
 /* Rank 0 after the gather: tiles_dev = world * rt_max_tiles_per_rank()*32*32*3 bytes (rank-major, each block
- * as rt_render_device wrote it); rgb_out_dev = res_y*res_x*3 bytes row-major.  Enqueue only. */
+ * as rt_render_device wrote it); rgb_out_dev = res_y*res_x*3 bytes row-major.  Enqueue only.  world == 1: the one
+ * block is the row-major image already and is copied (nothing happens when both pointers are equal). */
 int rt_assemble_tiles(rt_ctx* ctx, const void* tiles_dev, int32_t world, void* rgb_out_dev);
 
 /* Blocks until everything enqueued on the context's stream has finished.  RT_ERR_CAPACITY if the most recent frame found a

@@ -1459,6 +1459,12 @@ int rt_assemble_tiles(rt_ctx* c, const void* tiles_dev, int32_t world, void* rgb
     if (!c->have_scene) return c->fail(RT_ERR_STATE, "assemble before rt_upload_scene");
     if (world != c->world) return c->fail(RT_ERR_ARG, "world %d differs from the context's shard setting %d", world, c->world);
     RT_HIP(c, hipSetDevice(c->device));
+    if (world == 1) {
+        // an unsharded context writes the row-major image itself: its one "block" is copied, not re-ordered
+        if (tiles_dev != rgb_out_dev)
+            RT_HIP(c, hipMemcpyAsync(rgb_out_dev, tiles_dev, (size_t)c->camera.res_x * (size_t)c->camera.res_y * 3, hipMemcpyDeviceToDevice, c->stream));
+        return RT_OK;
+    }
     rt_launch_assemble(c->stream, (const unsigned char*)tiles_dev, world, c->max_tiles, c->tiles_x, c->tiles_y,
                        (int)c->camera.res_x, (int)c->camera.res_y, (unsigned char*)rgb_out_dev);
     RT_HIP(c, hipGetLastError());

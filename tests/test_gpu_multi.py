@@ -73,3 +73,22 @@ def test_command_line_front_end_with_several_gpus(tmp_path, textures_dir):
     img = ref_runner.parse_p3(tmp_path / "o.ppm")
     gold = np.load(cases.GOLDEN / "deterministic.npz")[cases.case_id("ref", [])].astype(np.int32)
     assert np.array_equal(img, gold)
+
+
+def test_bench_frames_through_an_rccl_group_of_one_rank(textures_dir):
+    """The N > 1 frame path of bench.py (pipelined gather on the communicator's stream, re-ordering, barriers) with the
+    only RCCL group a one-GPU box can form: one rank.  The last timed frame must be the frame a plain context renders."""
+    import json
+    import sys
+    import zlib
+    p = subprocess.run([sys.executable, str(cases.ROOT / "bench.py"), "--rehearse-rccl", "--steps", "7", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-scaling-4k"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["frames_in_flight"] == 3
+    import bench
+    wl = bench.WORKLOADS["config2"]
+    cfg, _ = api.parse_args(wl["flags"])
+    ls = api.LoadedScene(cases.reference_scene(*wl["res"]), cfg, textures_dir)
+    want = single(ls, cfg); ls.close()
+    assert line["config"]["image_crc32"] == zlib.crc32(np.ascontiguousarray(want).tobytes())
