@@ -263,9 +263,11 @@ int rt_render_device(rt_ctx* ctx, const rt_config* cfg, void* rgb_out_dev, rt_st
  * event and instantiates no graph: it only enqueues on the context's stream.  The film is rendered in as many batches
  * as that array allows; RT_ERR_CAPACITY when it cannot hold the film's per-pixel sums plus one wavefront of samples
  * (at most about 3.9 million pixel slots of 16 bytes).  All contexts of one GPU share the array and its previous
- * contents are overwritten: calls that overlap on one GPU (two contexts, two streams) race; wait for one frame
- * (rt_synchronize) before the next call on that GPU starts.  The scene must have been uploaded before (the uploads
- * do allocate). */
+ * contents are overwritten, so the array has one owner at a time: the context that calls this function owns it until
+ * its next rt_synchronize (or rt_destroy); frames of the owner follow each other on its stream, and any OTHER context
+ * of that GPU that calls meanwhile gets RT_ERR_STATE and enqueues nothing.  (Changing the owner's stream between two
+ * such frames without a synchronisation in between is the caller's race.)  The scene must have been uploaded before
+ * (the uploads do allocate). */
 int rt_render_device_noalloc(rt_ctx* ctx, const rt_config* cfg, void* rgb_out_dev);
 uint64_t rt_noalloc_capacity(void);
 

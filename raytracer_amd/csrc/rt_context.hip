@@ -275,6 +275,7 @@ struct rt_ctx {
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap = 1;
+    int walk_stats = 0;                      // development: kernels built with RT_WALK_STATS count their steps (rt_debug_walk_stats)
     void drop_graphs() {
         for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
         graphs.clear(); ++generation;
@@ -308,6 +309,7 @@ struct rt_ctx {
 #define RT_HIP(ctx, call) RT_TRY((ctx)->hip((call), #call))
 
 static hipError_t lookup_scratch(int device);
+static void release_scratch(rt_ctx* c);
 
 extern "C" {
 
@@ -338,6 +340,7 @@ void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    release_scratch(c);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -399,6 +402,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "bundle_reflections") == 0) { c->bundle_reflections = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "replicate_reflections") == 0) { c->replicate_reflections = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "overlap") == 0) { c->overlap = value != 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "walk_stats") == 0) { c->walk_stats = value != 0; c->drop_graphs(); return RT_OK; }
     return c->fail(RT_ERR_ARG, "unknown option %s", name);
 }
 
@@ -412,6 +416,7 @@ int rt_synchronize(rt_ctx* c) {
     unsigned long long flag = 0;
     if (c->last_flag) RT_HIP(c, hipMemcpyAsync(&flag, c->last_flag, sizeof flag, hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    release_scratch(c);                             // frames of rt_render_device_noalloc are complete: the GPU's scratch array is free again
     if (flag) return c->fail(RT_ERR_CAPACITY, "a work buffer overflowed during a frame; its image is incomplete");
     return RT_OK;
 }
@@ -1092,6 +1097,16 @@ static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
 enum { RT_MAX_DEVICES = 64 };
 static unsigned char* g_scratch_ptr[RT_MAX_DEVICES];       // per device: address of that GPU's copy of `scratch`
 static std::atomic<int> g_scratch_state[RT_MAX_DEVICES];   // 0 = not looked up, 1 = ready, -1 = lookup failed
+// Every context of a GPU shares that GPU's array.  The context whose frames may still be using it owns it from its first
+// rt_render_device_noalloc until its next rt_synchronize (or rt_destroy); another context that asks meanwhile is refused
+// instead of overwriting a frame in flight.  Frames of ONE context are ordered by its stream and may follow each other.
+static std::atomic<rt_ctx*> g_scratch_owner[RT_MAX_DEVICES];
+
+static void release_scratch(rt_ctx* c) {
+    if (c->device < 0 || c->device >= RT_MAX_DEVICES) return;
+    rt_ctx* me = c;
+    if (g_scratch_owner[c->device].compare_exchange_strong(me, nullptr)) c->last_flag = nullptr;   // (the flag word lies in the array)
+}
 
 // device must be current
 static hipError_t lookup_scratch(int device) {
@@ -1193,6 +1208,12 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
 
     DevWork w; std::memset(&w, 0, sizeof w);
     if (noalloc) {
+        // the frame fits: take the GPU's array unless another context's frames may still be in it
+        rt_ctx* owner = nullptr;
+        const bool took = g_scratch_owner[c->device].compare_exchange_strong(owner, c);
+        if (!took && owner != c)
+            return c->fail(RT_ERR_STATE, "rt_render_device_noalloc: another context's frame may still be using this GPU's scratch array "
+                                         "(call rt_synchronize on that context first)");
         // carve the scratch block: fixed part first, then the batch buffers (sizes as in plan_bytes)
         unsigned char* q = arena;
         auto take = [&](size_t bytes) { unsigned char* r = q; q += al(bytes); return r; };
@@ -1206,7 +1227,10 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         w.n_pix = (int*)take(cap_pix * 4);
         w.shadow = (float*)take(plan.cap_shadow * 4);
         w.link = (int*)take(cap_links * 4);
-        if ((size_t)(q - arena) > RT_NOALLOC_BYTES) return c->fail(RT_ERR_CAPACITY, "rt_render_device_noalloc: work plan exceeds the scratch array");
+        if ((size_t)(q - arena) > RT_NOALLOC_BYTES) {
+            if (took) release_scratch(c);
+            return c->fail(RT_ERR_CAPACITY, "rt_render_device_noalloc: work plan exceeds the scratch array");
+        }
     } else {
         const bool grow = cap_nodes > c->n_a.n || plan.cap_slots > c->n_col.n || cap_links > c->link.n || cap_rays > c->q_a[0].n || (size_t)n_slots > c->accum.n ||
                           (f.textures && cap_nodes > c->n_uv.n) || plan.cap_shadow > c->shadow.n || cap_pix > c->n_pix.n ||
@@ -1237,6 +1261,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         w.shadow = c->shadow.p; w.link = c->link.p; w.accum = c->accum.p; w.ctr = c->ctr.p; w.stats = c->stats.p;
     }
     w.cap_nodes = (unsigned)cap_nodes;
+    c->scene.walk_stats = c->walk_stats ? w.stats + RT_S_WALK : nullptr;
     c->last_flag = w.stats + RT_S_ERR;
     for (int d = 0; d <= D + 2 && d < RT_MAX_LEVELS; ++d) {
         w.node_off[d] = (int)node_off[(size_t)std::min(d, D + 1)]; w.link_off[d] = (int)link_off[(size_t)d];
@@ -1428,6 +1453,17 @@ int rt_render_device_noalloc(rt_ctx* c, const rt_config* cfg, void* rgb_out_dev)
 }
 
 uint64_t rt_noalloc_capacity(void) { return RT_NOALLOC_BYTES; }
+
+// Development aid, not part of include/rt_api.h: the step counters of the last frame rendered with the option
+// "walk_stats" by a library whose kernels were built with -DRT_WALK_STATS (zeros otherwise).  out[k] = lanes, out[16 + k] = wavefronts.
+int rt_debug_walk_stats(rt_ctx* c, uint64_t* out32) {
+    if (!c || !out32) return RT_ERR_ARG;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (!c->stats.p || c->stats.n < RT_S_TOTAL) { std::memset(out32, 0, 32 * sizeof(uint64_t)); return RT_OK; }
+    RT_HIP(c, hipMemcpy(out32, c->stats.p + RT_S_WALK, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
 
 int rt_render(rt_ctx* c, const rt_config* cfg, uint8_t* rgb_out, rt_stats* stats) {
     if (!c || !cfg || !rgb_out) return RT_ERR_ARG;

@@ -10,6 +10,29 @@
 #include <float.h>
 #include <math.h>
 
+// This file is compiled once per PART (see the Makefile): every part holds the shared device code and instantiates one
+// family of kernels together with its launcher, so the parts build side by side.
+//   RT_PART_KIND 0: shade / finalize / assemble / sort keys / frame start, and the public launchers that pick a part
+//                1: k_extend   2: k_primary_shaded   3: k_shadow          RT_PART_SUB: the kernels' SUB argument (0, 1, 2)
+#ifndef RT_PART_KIND
+#error "compile with -DRT_PART_KIND=<0..3> -DRT_PART_SUB=<0..2>"
+#endif
+#ifndef RT_PART_SUB
+#define RT_PART_SUB 0
+#endif
+#define RT_CAT2(a, b) a##b
+#define RT_CAT(a, b) RT_CAT2(a, b)
+
+// Development builds (-DRT_WALK_STATS): counts of the walk's steps, per lane and per wavefront, added to
+// DevScene::walk_stats[k] / [16 + k] (read back with rt_debug_walk_stats).  Expands to nothing otherwise.
+#ifdef RT_WALK_STATS
+#define RT_WS(sc, k) do { if ((sc).walk_stats) { const unsigned long long m__ = __ballot(1); \
+    if ((int)__lane_id() == __ffsll((long long)m__) - 1) { atomicAdd(&(sc).walk_stats[k], (unsigned long long)__popcll(m__)); atomicAdd(&(sc).walk_stats[16 + (k)], 1ull); } } } while (0)
+#else
+#define RT_WS(sc, k) do { } while (0)
+#endif
+enum { WS_BOX = 0, WS_GROUP = 1, WS_STEP = 2, WS_PLANE = 3, WS_CUBE = 4, WS_CUBE_EXACT = 5, WS_SPHERE = 6, WS_RETRY = 7, WS_RUN = 8, WS_TRACE = 9 };
+
 #define DEVI __device__ __forceinline__
 #define RL_FN __device__ __forceinline__
 #include "ref_libm.h"
@@ -475,6 +498,7 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth
     const float4* __restrict__ base = sc.sub_nodes + (size_t)(MOTION ? 8 : 4) * (size_t)root;
     const int first_run = (1 << depth) - 1;                   // heap index the first run would have
     for (;;) {
+        RT_WS(sc, WS_STEP);
         const int level = 31 - __clz(h + 1);
         const bool wide = level + 2 <= depth;                 // the children are interior nodes: step to the grandchildren
         const bool runs = level + 2 >= depth;                 // what this step tests are runs of entries
@@ -518,6 +542,7 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (go4[k] && !(tn4[k] > prune_t)) {
+                    RT_WS(sc, WS_RUN);
                     const int slot0 = 4 * (root + kid0 + k - first_run);
                     const int4 ev = *(const int4*)(sc.sub_entries + slot0);
 #pragma unroll
@@ -526,9 +551,9 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth
                         if (entry == 0xffffffffu) break;
                         const int cls = (int)(entry >> 30), idx = (int)(entry & 0x3fffffffu);
                         float t; bool ok;
-                        if (cls == 0) ok = plane_test<false, FAST>(S.planes + 3 * idx, S.edges, nullptr, r, false, t, nullptr);
-                        else if (cls == 1) ok = cube_test<false, FAST>(S.cubes + 6 * idx, r, mb, false, t, nullptr);
-                        else ok = sphere_test<false, FAST>(S.spheres + 2 * idx, r, mb, false, t, nullptr);
+                        if (cls == 0) { RT_WS(sc, WS_PLANE); ok = plane_test<false, FAST>(S.planes + 3 * idx, S.edges, nullptr, r, false, t, nullptr); }
+                        else if (cls == 1) { RT_WS(sc, WS_CUBE); ok = cube_test<false, FAST>(S.cubes + 6 * idx, r, mb, false, t, nullptr); }
+                        else { RT_WS(sc, WS_SPHERE); ok = sphere_test<false, FAST>(S.spheres + 2 * idx, r, mb, false, t, nullptr); }
                         if (ok && (!leaf_rule || t >= 0.0f) && (t < best_t || (has && t == best_t && tested_earlier(sc, slot0 + e, best_slot)))) {
                             has = true; best_t = t; best_slot = slot0 + e; best.t = t; best.cls = cls; best.idx = idx;
                             if (ANY || t < stop_below) return true;
@@ -588,6 +613,7 @@ template <bool ANY, int SUB, bool FAST = false, bool TOGETHER = true>
 DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict__ nodes, const int4* __restrict__ leaves,
                 int* __restrict__ stack, const Ray& r, bool with_fallback, Best& best, float stop_below = -INFINITY) {
     const bool mb = f.motion_blur != 0;
+    RT_WS(sc, WS_TRACE);
     SubRay q; q.rcp = q.cn = q.cf = mk(0.0f, 0.0f, 0.0f); q.px = q.py = q.pz = true;
     if (SUB) q = make_sub_ray(sc, r);
     // the file-order set as its hierarchy reads it (records in hierarchy order): what best.idx of a file-order hit indexes
@@ -608,6 +634,7 @@ DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict_
                 int leaf = -1;
                 while (i < n) {
                     const float4 a = nodes[2 * i], b = nodes[2 * i + 1];
+                    RT_WS(sc, WS_BOX);
                     if (!slab<FAST>(r, a, b, rcp, fast_ok)) { i = f2i(a.w); continue; }
                     ++i;
                     leaf = f2i(b.w);
@@ -615,21 +642,25 @@ DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict_
                 }
                 if (leaf < 0) break;
                 const int4 l0 = leaves[2 * leaf], l1 = leaves[2 * leaf + 1];
+                RT_WS(sc, WS_GROUP);
                 if (test_group<ANY, SUB, FAST>(sc, sc.leafset, r, q, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, true, stop_below, stack, best)) { best.fileset = 0; return true; }
             }
         } else {
             while (i < n) {
                 float4 a = nodes[2 * i], b = nodes[2 * i + 1];
+                RT_WS(sc, WS_BOX);
                 if (!slab<FAST>(r, a, b, rcp, fast_ok)) { i = f2i(a.w); continue; }
                 int leaf = f2i(b.w);
                 ++i;
                 if (leaf >= 0) {
                     int4 l0 = leaves[2 * leaf], l1 = leaves[2 * leaf + 1];
+                    RT_WS(sc, WS_GROUP);
                     if (test_group<ANY, SUB, FAST>(sc, sc.leafset, r, q, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, true, stop_below, stack, best)) { best.fileset = 0; return true; }
                 }
             }
         }
         if (!with_fallback) return false;
+        RT_WS(sc, WS_RETRY);
         best.fileset = 1;
         return test_group<false, SUB, FAST>(sc, FS, r, q, mb, 0, FS.n_planes, 0, FS.n_cubes, 0, FS.n_spheres,
                                  sc.file_sub_root, sc.file_sub_depth, false, stop_below, stack, best);
@@ -1325,6 +1356,7 @@ DEVI void store_pixel(const DevFrame& f, unsigned char* __restrict__ out, int ti
     }
 }
 
+#if RT_PART_KIND == 0
 // ---------------------------------------------------------------------------------------------------------
 // shade + resolve for one recursion level, deepest level first: Blinn-Phong at the hit (raytracer.cpp:262-347),
 // then the parent's combination of its children's colours with both clamps (raytracer.cpp:436-503).  Level 0
@@ -1495,6 +1527,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, Dev
     if (f.count_stats) block_stat_add(&w.stats[RT_S_NODES], n_shaded, s_tmp);
 }
 
+#endif  // RT_PART_KIND == 0
+
 // ---------------------------------------------------------------------------------------------------------
 // Frames without recursion and with hard shadows - the reference's default render and its multi-sample flag sets
 // without -r / -ss - in one kernel: a lane generates its primary ray, traces it, sends one shadow ray per light from
@@ -1594,6 +1628,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
     block_stat_add(&w.stats[RT_S_NODES], (unsigned long long)n_hits, s_tmp);
 }
 
+#if RT_PART_KIND == 0
 // Secondary rays of crowded scenes, re-coalesced before they are traced.  The rays a level queues sit in the order their
 // parents were traced; neighbouring lanes then start at unrelated points and walk unrelated parts of the second-level
 // hierarchies (a wavefront of such rays costs two to three times one of neighbouring rays).  This kernel gives every
@@ -1662,9 +1697,69 @@ __global__ void k_assemble(const unsigned char* __restrict__ tiles, int world, i
     }
 }
 
+#endif  // RT_PART_KIND == 0
+
 } // namespace
 
 
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+// Per-part launchers: the part that instantiates a family of kernels exports the function that launches them; the
+// public launchers of rt_types.h (part 0) work out the dynamic LDS size and pick the part by the scene's SUB value.
+void rt_launch_extend_part0(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid, size_t lds, bool ldsp);
+void rt_launch_extend_part1(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid, size_t lds, bool ldsp);
+void rt_launch_extend_part2(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid, size_t lds, bool ldsp);
+void rt_launch_fused_part0(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid, size_t lds, bool ldsp);
+void rt_launch_fused_part1(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid, size_t lds, bool ldsp);
+void rt_launch_fused_part2(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid, size_t lds, bool ldsp);
+void rt_launch_shadow_part0(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, size_t lds, bool ldsp, int mode);
+void rt_launch_shadow_part1(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, size_t lds, bool ldsp, int mode);
+void rt_launch_shadow_part2(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, size_t lds, bool ldsp, int mode);
+
+#if RT_PART_KIND == 1
+void RT_CAT(rt_launch_extend_part, RT_PART_SUB)(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid, size_t lds, bool ldsp) {
+    constexpr int SUB = RT_PART_SUB;
+#define RT_EXTEND_LAUNCH(PRIMARY, LDSP) \
+    do { if (f.count_stats) hipLaunchKernelGGL((k_extend<PRIMARY, SUB, LDSP, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level); \
+         else hipLaunchKernelGGL((k_extend<PRIMARY, SUB, LDSP, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level); } while (0)
+    if (level == 0) {
+        if (SUB == 0 && ldsp) RT_EXTEND_LAUNCH(true, (SUB == 0));
+        else RT_EXTEND_LAUNCH(true, false);
+    } else {
+        if (SUB == 0 && ldsp) RT_EXTEND_LAUNCH(false, (SUB == 0));
+        else RT_EXTEND_LAUNCH(false, false);
+    }
+#undef RT_EXTEND_LAUNCH
+}
+#endif
+
+#if RT_PART_KIND == 2
+void RT_CAT(rt_launch_fused_part, RT_PART_SUB)(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid, size_t lds, bool ldsp) {
+    constexpr int SUB = RT_PART_SUB;
+#define RT_FUSED_LAUNCH(LDSP) \
+    do { if (f.count_stats) hipLaunchKernelGGL((k_primary_shaded<SUB, LDSP, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w); \
+         else hipLaunchKernelGGL((k_primary_shaded<SUB, LDSP, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w); } while (0)
+    if (SUB == 0 && ldsp) RT_FUSED_LAUNCH((SUB == 0));
+    else RT_FUSED_LAUNCH(false);
+#undef RT_FUSED_LAUNCH
+}
+#endif
+
+#if RT_PART_KIND == 3
+void RT_CAT(rt_launch_shadow_part, RT_PART_SUB)(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, size_t lds, bool ldsp, int mode) {
+    constexpr int SUB = RT_PART_SUB;
+#define RT_SHADOW_LAUNCH(LDSP) \
+    do { if (mode == 2) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 2>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); \
+         else if (mode == 1) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 1>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); \
+         else hipLaunchKernelGGL((k_shadow<SUB, LDSP, 0>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); } while (0)
+    if (SUB == 0 && ldsp) RT_SHADOW_LAUNCH((SUB == 0));
+    else RT_SHADOW_LAUNCH(false);
+#undef RT_SHADOW_LAUNCH
+}
+#endif
+
+#if RT_PART_KIND == 0
 // Start of a frame: zero the per-pixel sums (or, for frames that write their pixels directly, the image), the first
 // batch's counters and (optionally) the ray statistics in one launch instead of three fills.
 __global__ void k_begin_frame(uint4* __restrict__ zero, size_t n_words, int tail_bytes, int* __restrict__ ctr, unsigned long long* __restrict__ stats) {
@@ -1678,9 +1773,6 @@ __global__ void k_begin_frame(uint4* __restrict__ zero, size_t n_words, int tail
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// launchers
-// ---------------------------------------------------------------------------------------------------------
 // LDS per workgroup: the first-level nodes and leaf records (BVH mode) and, when any group of primitives has a
 // second-level hierarchy, one traversal stack per thread.  The kernels index from n_nodes / n_leaves, which the
 // context zeroes when no BVH is uploaded.
@@ -1694,54 +1786,35 @@ static size_t bvh_lds_bytes(const DevScene& sc, const DevFrame& f, bool file_set
     return b ? b : 16;
 }
 
+// SUB of the kernels that render this scene: 0 = no second-level hierarchy, 1 = nodes of 4 words, 2 = of 8 (boxes per time)
+static int scene_sub(const DevScene& sc) { return !sc.sub_nodes ? 0 : (sc.sub_stride == 8 ? 2 : 1); }
+
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {
-    size_t lds = bvh_lds_bytes(sc, f, !f.use_bvh || (level > 0 && f.fallback_full));
-    const bool sub = sc.sub_nodes != nullptr;
+    const size_t lds = bvh_lds_bytes(sc, f, !f.use_bvh || (level > 0 && f.fallback_full));
+    const int sub = scene_sub(sc);
     const bool ldsp = !sub && sc.lds_prims > 1;
-#define RT_EXTEND_LAUNCH(PRIMARY, SUB, LDSP) \
-    do { if (f.count_stats) hipLaunchKernelGGL((k_extend<PRIMARY, SUB, LDSP, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level); \
-         else hipLaunchKernelGGL((k_extend<PRIMARY, SUB, LDSP, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, level); } while (0)
-    const bool per_time = sc.sub_stride == 8;
-    if (level == 0) {
-        if (sub && per_time) RT_EXTEND_LAUNCH(true, 2, false);
-        else if (sub) RT_EXTEND_LAUNCH(true, 1, false);
-        else if (ldsp) RT_EXTEND_LAUNCH(true, 0, true);
-        else RT_EXTEND_LAUNCH(true, 0, false);
-    } else {
-        if (sub && per_time) RT_EXTEND_LAUNCH(false, 2, false);
-        else if (sub) RT_EXTEND_LAUNCH(false, 1, false);
-        else if (ldsp) RT_EXTEND_LAUNCH(false, 0, true);
-        else RT_EXTEND_LAUNCH(false, 0, false);
-    }
-#undef RT_EXTEND_LAUNCH
+    if (sub == 2) rt_launch_extend_part2(s, sc, f, w, level, grid, lds, false);
+    else if (sub == 1) rt_launch_extend_part1(s, sc, f, w, level, grid, lds, false);
+    else rt_launch_extend_part0(s, sc, f, w, level, grid, lds, ldsp);
 }
 
 void rt_launch_primary_shaded(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid) {
     const size_t lds = bvh_lds_bytes(sc, f, !f.use_bvh);
-    const bool sub = sc.sub_nodes != nullptr;
+    const int sub = scene_sub(sc);
     const bool ldsp = !sub && sc.lds_prims > 1;
-#define RT_FUSED_LAUNCH(SUB, LDSP) \
-    do { if (f.count_stats) hipLaunchKernelGGL((k_primary_shaded<SUB, LDSP, true>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w); \
-         else hipLaunchKernelGGL((k_primary_shaded<SUB, LDSP, false>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w); } while (0)
-    if (sub && sc.sub_stride == 8) RT_FUSED_LAUNCH(2, false);
-    else if (sub) RT_FUSED_LAUNCH(1, false);
-    else if (ldsp) RT_FUSED_LAUNCH(0, true);
-    else RT_FUSED_LAUNCH(0, false);
-#undef RT_FUSED_LAUNCH
+    if (sub == 2) rt_launch_fused_part2(s, sc, f, w, grid, lds, false);
+    else if (sub == 1) rt_launch_fused_part1(s, sc, f, w, grid, lds, false);
+    else rt_launch_fused_part0(s, sc, f, w, grid, lds, ldsp);
 }
 
 void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid) {
     const size_t lds = bvh_lds_bytes(sc, f, !f.use_bvh);
     const int mode = !f.soft_shadows ? 0 : (f.fast_samples ? 2 : 1);  // hard shadows are deterministic: always exact
-#define RT_SHADOW_LAUNCH(SUB, LDSP) \
-    do { if (mode == 2) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 2>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); \
-         else if (mode == 1) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 1>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); \
-         else hipLaunchKernelGGL((k_shadow<SUB, LDSP, 0>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); } while (0)
-    if (sc.sub_nodes && sc.sub_stride == 8) RT_SHADOW_LAUNCH(2, false);
-    else if (sc.sub_nodes) RT_SHADOW_LAUNCH(1, false);
-    else if (sc.lds_prims) RT_SHADOW_LAUNCH(0, true);
-    else RT_SHADOW_LAUNCH(0, false);
-#undef RT_SHADOW_LAUNCH
+    const int sub = scene_sub(sc);
+    const bool ldsp = !sub && sc.lds_prims != 0;
+    if (sub == 2) rt_launch_shadow_part2(s, sc, f, w, lv_begin, lv_end, grid, lds, false, mode);
+    else if (sub == 1) rt_launch_shadow_part1(s, sc, f, w, lv_begin, lv_end, grid, lds, false, mode);
+    else rt_launch_shadow_part0(s, sc, f, w, lv_begin, lv_end, grid, lds, ldsp, mode);
 }
 
 void rt_launch_sort_keys(hipStream_t s, const DevScene& sc, const DevWork& w, int level, unsigned* keys, unsigned* slots) {
@@ -1772,3 +1845,4 @@ void rt_launch_assemble(hipStream_t s, const unsigned char* tiles, int world, in
     int grid = (n + RT_BLOCK - 1) / RT_BLOCK; if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(RT_BLOCK), 0, s, tiles, world, max_tiles, tiles_x, tiles_y, width, height, out);
 }
+#endif  // RT_PART_KIND == 0

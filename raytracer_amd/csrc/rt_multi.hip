@@ -63,6 +63,8 @@ struct rt_multi {
     Rccl rccl;
     std::vector<ncclComm_t> comms;
     std::vector<hipEvent_t> done;            // per device: block rendered (memcpy transport only)
+    std::vector<hipEvent_t> copied;          // per device: block copied to the first device (memcpy transport only)
+    std::vector<char> copy_pending;          // ... and whether such a copy has been enqueued since the device's stream last waited for it
     std::string err;
     int width = 0, height = 0;
     bool uploaded = false;
@@ -88,6 +90,7 @@ rt_multi* rt_multi_create(int32_t n_devices, const int32_t* device_ids, uint64_t
     m->n = n_devices;
     m->devices.assign(device_ids, device_ids + n_devices);
     m->ctx.assign((size_t)n_devices, nullptr); m->block.assign((size_t)n_devices, nullptr); m->done.assign((size_t)n_devices, nullptr);
+    m->copied.assign((size_t)n_devices, nullptr); m->copy_pending.assign((size_t)n_devices, 0);
     std::vector<int> sorted = m->devices; std::sort(sorted.begin(), sorted.end());
     const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
     for (int i = 0; i < n_devices; ++i) {
@@ -95,7 +98,8 @@ rt_multi* rt_multi_create(int32_t n_devices, const int32_t* device_ids, uint64_t
         if (!m->ctx[(size_t)i]) { g_multi_create_error = std::string("rt_multi_create: device ") + std::to_string(m->devices[(size_t)i]) + ": " + rt_last_error(nullptr); rt_multi_destroy(m); return nullptr; }
         if (rt_set_shard(m->ctx[(size_t)i], i, n_devices) != RT_OK) { g_multi_create_error = rt_last_error(m->ctx[(size_t)i]); rt_multi_destroy(m); return nullptr; }
         (void)hipSetDevice(m->devices[(size_t)i]);
-        if (hipEventCreateWithFlags(&m->done[(size_t)i], hipEventDisableTiming) != hipSuccess) { g_multi_create_error = "rt_multi_create: hipEventCreate failed"; rt_multi_destroy(m); return nullptr; }
+        if (hipEventCreateWithFlags(&m->done[(size_t)i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&m->copied[(size_t)i], hipEventDisableTiming) != hipSuccess) { g_multi_create_error = "rt_multi_create: hipEventCreate failed"; rt_multi_destroy(m); return nullptr; }
     }
     if (distinct) {
         // one communicator per device, all made by this process (single-process multi-GPU)
@@ -115,6 +119,7 @@ void rt_multi_destroy(rt_multi* m) {
     m->free_buffers();
     for (int i = 0; i < m->n; ++i) {
         if (m->done[(size_t)i]) { (void)hipSetDevice(m->devices[(size_t)i]); (void)hipEventDestroy(m->done[(size_t)i]); }
+        if (m->copied[(size_t)i]) { (void)hipSetDevice(m->devices[(size_t)i]); (void)hipEventDestroy(m->copied[(size_t)i]); }
         if (m->ctx[(size_t)i]) rt_destroy(m->ctx[(size_t)i]);
     }
     delete m;
@@ -169,6 +174,15 @@ int rt_multi_upload(rt_multi* m, const rt_scene* scene, const rt_bvh_node* nodes
 int rt_multi_render_device(rt_multi* m, const rt_config* cfg) {
     if (!m || !cfg) return RT_ERR_ARG;
     if (!m->uploaded) return m->fail(RT_ERR_STATE, "rt_multi_render before rt_multi_upload");
+    // memcpy transport: the previous frame's block of device i is read by a copy on the FIRST device's stream; device i's
+    // stream must not start overwriting the block before that copy is done (frames may be enqueued back to back)
+    if (!m->use_rccl)
+        for (int i = 1; i < m->n; ++i)
+            if (m->copy_pending[(size_t)i]) {
+                RTM_TRY(m->hip(hipSetDevice(m->devices[(size_t)i]), "hipSetDevice"));
+                RTM_TRY(m->hip(hipStreamWaitEvent((hipStream_t)rt_get_stream(m->ctx[(size_t)i]), m->copied[(size_t)i], 0), "hipStreamWaitEvent"));
+                m->copy_pending[(size_t)i] = 0;
+            }
     for (int i = 0; i < m->n; ++i)
         if (rt_render_device(m->ctx[(size_t)i], cfg, m->block[(size_t)i], nullptr) != RT_OK)
             return m->fail(RT_ERR_HIP, std::string("device ") + std::to_string(m->devices[(size_t)i]) + ": " + rt_last_error(m->ctx[(size_t)i]));
@@ -180,12 +194,16 @@ int rt_multi_render_device(rt_multi* m, const rt_config* cfg) {
         return RT_OK;
     }
     if (m->use_rccl) {
+        // a group once opened is always closed: the first failure inside it is kept and reported after ncclGroupEnd
         RTM_TRY(m->nccl(m->rccl.GroupStart(), "ncclGroupStart"));
-        for (int i = 1; i < m->n; ++i) {
-            RTM_TRY(m->nccl(m->rccl.Recv(m->gathered + (size_t)i * bb, bb, kNcclUint8, i, m->comms[0], s0), "ncclRecv"));
-            RTM_TRY(m->nccl(m->rccl.Send(m->block[(size_t)i], bb, kNcclUint8, 0, m->comms[(size_t)i], (hipStream_t)rt_get_stream(m->ctx[(size_t)i])), "ncclSend"));
+        ncclResult_t first_bad = 0; const char* where = "";
+        for (int i = 1; i < m->n && first_bad == 0; ++i) {
+            first_bad = m->rccl.Recv(m->gathered + (size_t)i * bb, bb, kNcclUint8, i, m->comms[0], s0); where = "ncclRecv";
+            if (first_bad == 0) { first_bad = m->rccl.Send(m->block[(size_t)i], bb, kNcclUint8, 0, m->comms[(size_t)i], (hipStream_t)rt_get_stream(m->ctx[(size_t)i])); where = "ncclSend"; }
         }
-        RTM_TRY(m->nccl(m->rccl.GroupEnd(), "ncclGroupEnd"));
+        const ncclResult_t end = m->rccl.GroupEnd();
+        if (first_bad != 0) return m->nccl(first_bad, where);
+        RTM_TRY(m->nccl(end, "ncclGroupEnd"));
         RTM_TRY(m->hip(hipSetDevice(m->devices[0]), "hipSetDevice"));
         RTM_TRY(m->hip(hipMemcpyAsync(m->gathered, m->block[0], bb, hipMemcpyDeviceToDevice, s0), "hipMemcpyAsync"));
     } else {
@@ -197,6 +215,7 @@ int rt_multi_render_device(rt_multi* m, const rt_config* cfg) {
         for (int i = 0; i < m->n; ++i) {
             if (i) RTM_TRY(m->hip(hipStreamWaitEvent(s0, m->done[(size_t)i], 0), "hipStreamWaitEvent"));
             RTM_TRY(m->hip(hipMemcpyAsync(m->gathered + (size_t)i * bb, m->block[(size_t)i], bb, hipMemcpyDeviceToDevice, s0), "hipMemcpyAsync"));
+            if (i) { RTM_TRY(m->hip(hipEventRecord(m->copied[(size_t)i], s0), "hipEventRecord")); m->copy_pending[(size_t)i] = 1; }
         }
     }
     if (rt_assemble_tiles(m->ctx[0], m->gathered, m->n, m->image) != RT_OK) return m->fail(RT_ERR_HIP, rt_last_error(m->ctx[0]));

@@ -82,6 +82,7 @@ struct DevScene {
     int n_verts;                   // polygon vertices of all planes
     int lds_prims;                 // tiny scene: kernels keep the primitive records and materials in LDS
     float center[3], radius;       // sphere around the true bounds of everything in the scene
+    unsigned long long* walk_stats;  // development builds (RT_WALK_STATS): 32 counters behind the frame's statistics, else NULL
 };
 
 struct DevFrame {
@@ -171,7 +172,8 @@ enum { RT_C_TOTAL = RT_REGIONS * RT_CTR_REGION_INTS };
 // rays per hit, and with them their whole subtrees; every ray carries that multiplicity.
 enum { RT_S_PRIMARY = 0, RT_S_SHADOW, RT_S_REFLECT, RT_S_REFRACT, RT_S_NODES, RT_S_SHADOW_REF, RT_S_REFLECT_REF, RT_S_REFRACT_REF,
        RT_S_ERR = 8,               // non-zero when a capacity was exceeded during the frame
-       RT_S_TOTAL = 16 };
+       RT_S_WALK = 16,             // 32 step counters of development builds (see RT_WS in rt_kernels.hip)
+       RT_S_TOTAL = 48 };
 
 // 16-byte words the kernels copy into LDS when DevScene::lds_prims is set
 #define RT_LDS_PRIM_MAX_WORDS 384

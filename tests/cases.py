@@ -62,11 +62,13 @@ SCENES = {
     "ref120": lambda: reference_scene(120, 68),
     "glass": lambda: sg.glass_scene((200, 112)),
     "glass_tex": lambda: sg.glass_scene((200, 112), True),
+    "glass_tex120": lambda: sg.glass_scene((120, 68), True),
     "cluster16": lambda: sg.cluster_scene(16, 7, (200, 112)),
     "rand200": lambda: sg.random_scene(200, 42, (160, 90), rmin=0.2, rmax=0.6, transparent_frac=0.2, moving=True),
     # dense enough that the depth-8 tree's leaves hold tens of primitives (second-level hierarchy on the device)
     "rand300m": lambda: sg.random_scene(300, 5, (96, 54), rmin=0.15, rmax=0.45, moving=True, extent=6.0),
     "rand2k": lambda: sg.random_scene(2000, 11, (128, 72), rmin=0.15, rmax=0.5, transparent_frac=0.15, moving=True, extent=12.0),
+    "rand2k64": lambda: sg.random_scene(2000, 11, (64, 36), rmin=0.15, rmax=0.5, transparent_frac=0.15, moving=True, extent=12.0),
 }
 
 # Deterministic flag sets: the image is a pure function of scene + flags; the bar is +-1 LSB per channel.
@@ -131,6 +133,33 @@ STOCHASTIC = [
     ("glass_tex", ["-t", "-rd", "2", "-grs", "1", "-ss", "-sss", "256"]),
     ("bvh5", ["-r", "-grs", "1", "-ss", "-sss", "128"]),
 ]
+
+# Glossy reflection combined with soft shadows (every hit of a rndConeDirection ray runs computeSoftShadows,
+# raytracer.cpp:400-413 under :330-332), and the headline configuration at its own depth.  GPU side: the mean of
+# SEED_MEAN_SEEDS renders with `flags` and different seeds; golden side: ONE render of the reference binary with
+# `golden_flags` (more samples per estimate; the expectation is the same up to the clamps' non-linearity).
+SEED_MEAN = [
+    # (scene, flags of each GPU render, flags of the reference's render)
+    ("ref", ["-r", "-gr", "-grs", "16", "-ss", "-sss", "16"], ["-r", "-gr", "-grs", "64", "-ss", "-sss", "64"]),
+    ("glass_tex120", ["-t", "-rd", "2", "-gr", "-grs", "16", "-ss", "-sss", "16"], ["-t", "-rd", "2", "-gr", "-grs", "32", "-ss", "-sss", "64"]),
+    ("ref", ["-rd", "4", "-ss", "-sss", "16"], ["-rd", "4", "-grs", "1", "-ss", "-sss", "256"]),
+]
+SEED_MEAN_SEEDS = 16
+
+# The all-effects flag set of the largest configuration (-aa -dof -m -t -ss -r -gr together) on a crowded scene whose
+# primitives move inside second-level hierarchies.  The reference binary needs days for it; the CPU restatement renders
+# it in bands (make_seeded.py).  Two fixtures: the flag set itself with two different rand() seeds (the noise floor of
+# 64 samples per pixel), and the same estimators at 256 primary samples per pixel (own jitter, lens point and time each)
+# against which the mean of ALL_EFFECTS_SEEDS GPU renders is held.
+ALL_EFFECTS = ("rand2k64", ["-aa", "-aas", "4", "-dof", "-dofs", "4", "-m", "-mbs", "4", "-t", "-ss", "-sss", "16", "-r", "-gr", "-grs", "4"])
+ALL_EFFECTS_HIGH = ["-aa", "-aas", "256", "-dof", "-dofs", "1", "-m", "-mbs", "1", "-t", "-ss", "-sss", "16", "-r", "-gr", "-grs", "4"]
+ALL_EFFECTS_SEEDS = 16
+
+# Soft shadows under identical reflection rays at depth >= 2: the device traces the FIRST reflection of a path gr_samples
+# times and deeper ones once (rt_api.h, replicate_reflections); the mean image must still be the restatement's, whose
+# every level re-traces gr_samples rays with their own shadow samples (raytracer.cpp:400-432).
+DEEP_GLOSS = [("mirror", ["-rd", "3", "-grs", "4", "-ss", "-sss", "4"])]
+DEEP_GLOSS_SEEDS = 32
 
 # A crowded random scene with every effect that has a sample count switched on at once (moving primitives in
 # second-level hierarchies, soft shadows, reflection and refraction).  The reference needs hours for this frame on one

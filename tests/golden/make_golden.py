@@ -2,7 +2,7 @@
 
 Runs only where /root/reference is mounted (`make -C oracle ref` first).  Outputs are data only:
   deterministic.npz : uint8 [H,W,3] image per deterministic case of tests/cases.py
-  stochastic.npz    : uint8 [H,W,3] high-sample image per stochastic case
+  stochastic.npz    : uint8 [H,W,3] high-sample image per stochastic case, and per golden flag set of cases.SEED_MEAN
   config1_1080p.npz : the reference's default render of its own scene.json at 1920x1080
   kat_primitives.npz: known answers of Sphere/Cube/Plane::intersect, their getAABB and AABB::intersect on seeded random
                       inputs, printed by oracle/_ref/ref_kat (`make -C oracle kat`; `make_golden.py kat` regenerates)
@@ -40,18 +40,20 @@ def make_kat(n=1500):
 def main():
     if sys.argv[1:] == ["kat"]:
         make_kat(); return
+    sto_jobs = cases.STOCHASTIC + [(s, g) for s, _, g in cases.SEED_MEAN]
     if len(sys.argv) > 1:            # regenerate only the named cases, keep the rest
-        for fname, catalogue in (("deterministic.npz", cases.DETERMINISTIC), ("stochastic.npz", cases.STOCHASTIC)):
+        for fname, catalogue in (("deterministic.npz", cases.DETERMINISTIC), ("stochastic.npz", sto_jobs)):
             have = dict(np.load(HERE / fname))
             want = {cases.case_id(s, f) for s, f in catalogue}
-            for job in catalogue:
-                if cases.case_id(*job) in sys.argv[1:]:
-                    k, v, secs = run(job); have[k] = v; print(f"{k:60s} {secs:8.2f} s")
+            named = [job for job in catalogue if cases.case_id(*job) in sys.argv[1:]]
+            with ProcessPoolExecutor(max_workers=4) as ex:
+                for k, v, secs in ex.map(run, named):
+                    have[k] = v; print(f"{k:60s} {secs:8.2f} s", flush=True)
             np.savez_compressed(HERE / fname, **{k: v for k, v in have.items() if k in want})
         return
     with ProcessPoolExecutor(max_workers=6) as ex:
         det = list(ex.map(run, cases.DETERMINISTIC))
-        sto = list(ex.map(run, cases.STOCHASTIC))
+        sto = list(ex.map(run, sto_jobs))
     np.savez_compressed(HERE / "deterministic.npz", **{k: v for k, v, _ in det})
     np.savez_compressed(HERE / "stochastic.npz", **{k: v for k, v, _ in sto})
     for k, _, s in det + sto:

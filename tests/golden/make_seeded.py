@@ -6,7 +6,10 @@ binary exists).  Output: seeded.npz
   mirror_mean, mirror_var     : per-pixel mean image and variance (summed over channels) with cases.MIRROR_FLAGS
   banded_<case>               : uint8 images of cases.STOCHASTIC_BANDED, rendered in cases.BANDS horizontal bands (band b
                                 with rand() seed 1 + b), for flag sets the reference binary needs hours for
-Usage: make_seeded.py [floor] [mirror] [banded]   (default: all; parts not named are kept from the existing file)
+  alleffects_seed1 / _seed2   : cases.ALL_EFFECTS rendered in bands with two different sets of rand() seeds
+  alleffects_high             : the same estimators with cases.ALL_EFFECTS_HIGH (256 primary samples per pixel)
+  deep_mean_<scene>_<flags>   : float32 mean image over cases.DEEP_GLOSS_SEEDS rand() seeds of cases.DEEP_GLOSS
+Usage: make_seeded.py [floor] [mirror] [banded] [alleffects] [deep]   (default: all; parts not named are kept from the existing file)
 """
 import sys
 from concurrent.futures import ProcessPoolExecutor
@@ -36,19 +39,28 @@ def mirror_stats(pool_map=map):
 
 
 def render_band(job):
-    scene, flags, band = job
+    scene, flags, band = job[:3]
+    seed0 = job[3] if len(job) > 3 else 1
     text = cases.SCENES[scene]()
     w, h = ref_runner.get_resolution(text)
     y0, y1 = (h * band) // cases.BANDS, (h * (band + 1)) // cases.BANDS
-    img = oracle.render(text, flags, TEX, rand_seed=1 + band, window=(0, y0, w, y1))[0]
+    img = oracle.render(text, flags, TEX, rand_seed=seed0 + band, window=(0, y0, w, y1))[0]
     return y0, y1, img[y0:y1]
 
 
+def banded(ex, scene, flags, seed0=1):
+    w, h = ref_runner.get_resolution(cases.SCENES[scene]())
+    img = np.zeros((h, w, 3), dtype=np.uint8)
+    for y0, y1, band in ex.map(render_band, [(scene, flags, b, seed0) for b in range(cases.BANDS)]):
+        img[y0:y1] = band
+    return img
+
+
 def main():
-    parts = set(sys.argv[1:]) or {"floor", "mirror", "banded"}
+    parts = set(sys.argv[1:]) or {"floor", "mirror", "banded", "alleffects", "deep"}
     path = HERE / "seeded.npz"
     out = dict(np.load(path)) if path.exists() else {}
-    with ProcessPoolExecutor(max_workers=7) as ex:
+    with ProcessPoolExecutor(max_workers=int(__import__("os").environ.get("SEEDED_WORKERS", "7"))) as ex:
         if "floor" in parts:
             jobs = [(s, f, seed) for s, f in cases.NOISE_FLOOR for seed in (1, 2)]
             for (s, f, seed), img in zip(jobs, ex.map(render, jobs)):
@@ -66,6 +78,17 @@ def main():
                 for y0, y1, band in ex.map(render_band, [(s, f, b) for b in range(cases.BANDS)]):
                     img[y0:y1] = band
                 out[f"banded_{cases.case_id(s, f)}"] = img
+        if "alleffects" in parts:
+            scene, flags = cases.ALL_EFFECTS
+            out["alleffects_seed1"] = banded(ex, scene, flags, 1)
+            out["alleffects_seed2"] = banded(ex, scene, flags, 1001)
+            out["alleffects_high"] = banded(ex, scene, cases.ALL_EFFECTS_HIGH, 2001)
+        if "deep" in parts:
+            for scene, flags in cases.DEEP_GLOSS:
+                seeds = range(1, cases.DEEP_GLOSS_SEEDS + 1)
+                imgs = np.stack(list(ex.map(render, [(scene, flags, s) for s in seeds]))).astype(np.float64)
+                out[f"deep_mean_{cases.case_id(scene, flags)}"] = imgs.mean(axis=0).astype(np.float32)
+                out[f"deep_var_{cases.case_id(scene, flags)}"] = imgs.var(axis=0).sum(axis=2).astype(np.float32)
     np.savez_compressed(path, **out)
     for k, v in out.items():
         print(k, v.shape, v.dtype)

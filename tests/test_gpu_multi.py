@@ -45,6 +45,28 @@ def test_frame_split_over_a_device_list_is_the_single_device_frame(devices, text
     m.close(); ls.close()
 
 
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0]])
+def test_frames_enqueued_back_to_back_do_not_overwrite_blocks_still_being_gathered(devices, textures_dir):
+    """rt_multi_render_device only enqueues.  Three frames with different seeds before one synchronisation: with the
+    device-copy transport a block is read by a copy on the first device's stream, so the next frame of its own device
+    has to wait for that copy; the image left behind must be the last frame's."""
+    cfg, _ = api.parse_args(["-r", "-ss", "-sss", "4", "-aa", "-aas", "2"])
+    ls = api.LoadedScene(cases.reference_scene(1920, 1080), cfg, textures_dir)
+    m = api.MultiRenderer(devices); m.upload(ls)
+    last = None
+    for rep in range(3):
+        for seed in (5, 6, 7):
+            c = copy.copy(cfg); c.seed = seed + 10 * rep
+            m.render_device(c); last = c
+    m.synchronize()
+    n = 1080 * 1920 * 3
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    import ctypes as C
+    C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(dev.data_ptr()), C.c_void_p(m.image_ptr()), C.c_size_t(n), C.c_int(3))
+    assert np.array_equal(dev.cpu().numpy().reshape(1080, 1920, 3), single(ls, last))
+    m.close(); ls.close()
+
+
 def test_multi_errors_and_no_bvh():
     with pytest.raises(api.RtError):
         api.MultiRenderer([0, 99])                      # no such device

@@ -62,3 +62,28 @@ def test_noalloc_entry_rejects_what_does_not_fit():
     r.render_device(cfg, out.data_ptr()); r.synchronize()               # the allocating entry point still works
     assert int(out.max()) > 0
     ls.close(); r.close()
+
+
+def test_noalloc_entry_refuses_a_second_context_while_a_frame_may_be_in_flight(textures_dir):
+    """One scratch array per GPU: the context that rendered into it owns it until its rt_synchronize; another context
+    asking meanwhile gets RT_ERR_STATE instead of overwriting the frame, and the array is free again afterwards."""
+    cfg, _ = api.parse_args(["-r", "-ss", "-sss", "4"]); cfg.seed = 3
+    ls = api.LoadedScene(cases.reference_scene(640, 360), cfg, textures_dir)
+    a, b = api.Renderer(0), api.Renderer(0)
+    a.upload(ls); b.upload(ls)
+    n = a.out_bytes()
+    out_a = torch.zeros(n, dtype=torch.uint8, device="cuda"); out_b = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    want = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    a.render_device(cfg, want.data_ptr()); a.synchronize()
+    a.render_device_noalloc(cfg, out_a.data_ptr())
+    a.render_device_noalloc(cfg, out_a.data_ptr())                     # the same context again: ordered by its stream
+    with pytest.raises(api.RtError) as e:
+        b.render_device_noalloc(cfg, out_b.data_ptr())
+    assert e.value.code == -3 and "another context" in str(e.value)
+    a.synchronize()
+    b.render_device_noalloc(cfg, out_b.data_ptr()); b.synchronize()     # free again
+    assert np.array_equal(out_a.cpu().numpy(), want.cpu().numpy()) and np.array_equal(out_b.cpu().numpy(), want.cpu().numpy())
+    b.render_device_noalloc(cfg, out_b.data_ptr())                      # b owns the array again and is destroyed with a frame enqueued
+    b.close()                                                         # destroying the owner releases the array too
+    a.render_device_noalloc(cfg, out_a.data_ptr()); a.synchronize()
+    ls.close(); a.close()
