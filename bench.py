@@ -304,7 +304,12 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
             from raytracer_amd import scenegen as sg
             moving = bool(cfg.motion_blur) and os.environ.get("RT_BENCH_STATIC", "") != "1"
             ls = api.ArrayScene(sg.random_prims(wl["n"], wl.get("seed", 42), moving=moving), (W, H), moving=moving)
-    ls = rdist.broadcast_scene(ls, bool(cfg.bvh), 0, on_dev)
+    # Over RCCL the scene travels device to device: rank 0 uploads (and builds the second-level hierarchies on its GPU) once,
+    # the other ranks adopt the layout and receive every device array by broadcast; no rank but 0 touches host scene data.
+    # (gloo rehearsals move the flat host arrays instead and every rank uploads its copy.)
+    device_scene = multi and args.backend != "gloo"
+    if not device_scene:
+        ls = rdist.broadcast_scene(ls, bool(cfg.bvh), 0, on_dev)
     # Frames in flight: consecutive frames are independent, so P contexts (each with its own work buffers and stream)
     # render them concurrently; a frame's small launches (deep recursion levels) then fill the other frames' gaps.
     # Four by default: one per hardware queue of the process (more share queues and lose again).  Not used for frames
@@ -334,7 +339,12 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
         return rr
 
     r = new_renderer()
-    r.upload(ls, with_bvh=bool(cfg.bvh))
+    if device_scene:
+        if rank == 0:
+            r.upload(ls, with_bvh=bool(cfg.bvh))
+        rdist.broadcast_device_scene(r, 0, dev)
+    else:
+        r.upload(ls, with_bvh=bool(cfg.bvh))
     r.set_shard(rank, world)
     upload_s = time.perf_counter() - t_load
     # Everything of a step runs on the context's own stream, which torch sees as an external stream (the RCCL gather
@@ -350,7 +360,11 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     ctxs = [(r, stream, block)]
     for _ in range(P - 1):
         r2 = new_renderer()
-        r2.upload(ls, with_bvh=bool(cfg.bvh)); r2.set_shard(rank, world)
+        if device_scene:
+            r2.adopt_from(r)                          # the rank's other contexts copy the first one's arrays on the device
+        else:
+            r2.upload(ls, with_bvh=bool(cfg.bvh))
+        r2.set_shard(rank, world)
         s2 = torch.cuda.ExternalStream(r2.stream_handle(), device=dev)
         ctxs.append((r2, s2, torch.empty_like(block)))
 
@@ -512,7 +526,8 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     torch.cuda.set_stream(torch.cuda.default_stream(dev))      # the contexts' streams die with them
     for rr, _, _ in ctxs:
         rr.close()
-    ls.close()
+    if ls is not None:
+        ls.close()
     del pipes, ctxs, block, image, keep
     torch.cuda.synchronize(dev)
     torch.cuda.empty_cache()

@@ -282,6 +282,25 @@ int rt_synchronize(rt_ctx* ctx);
 
 const char* rt_last_error(const rt_ctx* ctx);   /* ctx may be NULL: error of the last failed rt_create */
 
+/* ---- a device-resident scene handed from one context to others (no counterpart in the reference) ------------------
+ * After its uploads a context holds every array the kernels read in its GPU's memory.  Another context - on another GPU
+ * of the node, in this process or in another rank's - takes the scene over without parsing, building or uploading:
+ *   source:    rt_export_scene_layout(src, buf, rt_scene_layout_bytes())     a small POD blob (no addresses in it)
+ *   receivers: rt_adopt_scene_layout(dst, buf, bytes)                        allocates the arrays, contents undefined
+ *   both:      rt_scene_array(ctx, k, &ptr, &bytes) for k < rt_scene_array_count(ctx): the k-th array on either side;
+ *              the caller moves the bytes device to device (ncclBroadcast / torch.distributed.broadcast / hipMemcpy)
+ *              and synchronises before the first render.
+ * rt_adopt_scene_from does all of it between two contexts of one process with device copies.  An adopted scene
+ * renders exactly the source's frames; rt_upload_bvh on it fails with RT_ERR_STATE (upload the tree on the source and
+ * adopt again), rt_upload_scene replaces it.  The layout is only valid between builds of the same library. */
+uint64_t rt_scene_layout_bytes(void);
+int rt_export_scene_layout(rt_ctx* src, void* layout, uint64_t capacity);
+int rt_adopt_scene_layout(rt_ctx* dst, const void* layout, uint64_t bytes);
+int rt_scene_layout_resolution(const void* layout, uint64_t bytes, int32_t* width, int32_t* height);   /* film size the layout carries */
+int32_t rt_scene_array_count(const rt_ctx* ctx);
+int rt_scene_array(rt_ctx* ctx, int32_t k, void** dev_ptr, uint64_t* bytes);
+int rt_adopt_scene_from(rt_ctx* dst, rt_ctx* src);
+
 /* ---- several GPUs of one node, one process (no counterpart in the reference, which is single-threaded) ------------
  * The render loop of raytracer.cpp:109-193 split over n devices: device k renders the 32x32 tiles with
  * (tile_x + tile_y) % n == k, the tile blocks are gathered to the first device of the list with RCCL (one group of
@@ -292,8 +311,11 @@ const char* rt_last_error(const rt_ctx* ctx);   /* ctx may be NULL: error of the
 typedef struct rt_multi rt_multi;
 rt_multi* rt_multi_create(int32_t n_devices, const int32_t* device_ids, uint64_t workspace_bytes_per_device);
 void rt_multi_destroy(rt_multi* m);
-int rt_multi_set_option(rt_multi* m, const char* name, int64_t value);             /* rt_set_option on every context */
-/* rt_upload_scene + rt_upload_bvh on every device (nodes == NULL: no BVH), one host thread per device. */
+int rt_multi_set_option(rt_multi* m, const char* name, int64_t value);             /* rt_set_option on every context; "device_broadcast" is rt_multi's own */
+/* The scene and the tree of raytracer.cpp:55-79, once per frame set (nodes == NULL: no BVH): rt_upload_scene +
+ * rt_upload_bvh on the first device, whose finished device arrays are then broadcast to the other devices (the layout
+ * calls below + one ncclBroadcast per array over xGMI; device copies for a repeated device id).  With the option
+ * "device_broadcast" set to 0 every device uploads and builds for itself instead, one host thread per device. */
 int rt_multi_upload(rt_multi* m, const rt_scene* scene, const rt_bvh_node* nodes, int32_t n_nodes, const int32_t* prim_ids, int32_t n_prim_ids);
 /* One frame: rgb_out (host) receives res_y*res_x*3 bytes as rt_render writes them.  rt_multi_render_device only
  * enqueues; the frame is in rt_multi_image() (memory of the first device) after rt_multi_synchronize(). */

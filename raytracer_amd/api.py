@@ -114,6 +114,8 @@ API_SYMBOLS = ["rt_default_config", "rt_create", "rt_destroy", "rt_set_stream", 
                "rt_set_shard", "rt_local_tiles", "rt_max_tiles_per_rank", "rt_render", "rt_render_device",
                "rt_assemble_tiles", "rt_synchronize", "rt_last_error", "rt_render_device_noalloc", "rt_noalloc_capacity",
                "rt_alloc_image", "rt_free_image",
+               "rt_scene_layout_bytes", "rt_export_scene_layout", "rt_adopt_scene_layout", "rt_scene_layout_resolution",
+               "rt_scene_array_count", "rt_scene_array", "rt_adopt_scene_from",
                "rt_multi_create", "rt_multi_destroy", "rt_multi_set_option", "rt_multi_upload", "rt_multi_render", "rt_multi_render_device",
                "rt_multi_synchronize", "rt_multi_image", "rt_multi_context", "rt_multi_uses_rccl", "rt_multi_last_error"]
 HOST_SYMBOLS = ["rt_host_parse_args", "rt_host_parse_scene", "rt_host_load_scene", "rt_host_free_scene",
@@ -160,6 +162,13 @@ def lib():
     L.rt_assemble_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.rt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(Config), C.c_void_p]
     L.rt_noalloc_capacity.argtypes = []; L.rt_noalloc_capacity.restype = C.c_uint64
+    L.rt_scene_layout_bytes.argtypes = []; L.rt_scene_layout_bytes.restype = C.c_uint64
+    L.rt_export_scene_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.rt_adopt_scene_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.rt_scene_array_count.argtypes = [C.c_void_p]; L.rt_scene_array_count.restype = C.c_int32
+    L.rt_scene_array.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.rt_adopt_scene_from.argtypes = [C.c_void_p, C.c_void_p]
+    L.rt_scene_layout_resolution.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rt_alloc_image.argtypes = [C.c_uint64]; L.rt_alloc_image.restype = C.c_void_p
     L.rt_free_image.argtypes = [C.c_void_p]; L.rt_free_image.restype = None
     L.rt_multi_create.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.c_uint64]; L.rt_multi_create.restype = C.c_void_p
@@ -455,6 +464,14 @@ def write_ppm(path: str, img: np.ndarray, maxval: int = 255, binary: bool = Fals
 
 # ---- render boundary -------------------------------------------------------------------------------------
 
+def struct_res(layout: bytes) -> tuple[int, int]:
+    """Film size inside a scene layout blob (rt_export_scene_layout), read by the library (the blob's struct is private to it)."""
+    w, h = C.c_int32(), C.c_int32()
+    if lib().rt_scene_layout_resolution(layout, len(layout), C.byref(w), C.byref(h)) != RT_OK:
+        raise RtError(-1, "not a scene layout of this library version")
+    return int(w.value), int(h.value)
+
+
 class Renderer:
     """One rt_ctx on one GPU."""
 
@@ -491,6 +508,34 @@ class Renderer:
     def set_shard(self, rank: int, world: int):
         self._check(lib().rt_set_shard(self._ctx, rank, world))
         self.rank, self.world = rank, world
+
+    # ---- the device-resident scene handed to other contexts (rt_export_scene_layout and friends) ----
+    def export_layout(self) -> bytes:
+        """After upload(): the small blob another context adopts before the device arrays are sent to it."""
+        n = int(lib().rt_scene_layout_bytes())
+        buf = C.create_string_buffer(n)
+        self._check(lib().rt_export_scene_layout(self._ctx, buf, n))
+        return buf.raw
+
+    def adopt_layout(self, layout: bytes):
+        """Allocates the scene's device arrays as `layout` describes them; their contents must be sent next."""
+        self._check(lib().rt_adopt_scene_layout(self._ctx, layout, len(layout)))
+        w, h = struct_res(layout)
+        self.width, self.height = w, h
+
+    def scene_arrays(self) -> list[tuple[int, int]]:
+        """(device pointer, bytes) of every array of the exported / adopted scene, in the same order on both sides."""
+        out = []
+        for k in range(lib().rt_scene_array_count(self._ctx)):
+            p, n = C.c_void_p(), C.c_uint64()
+            self._check(lib().rt_scene_array(self._ctx, k, C.byref(p), C.byref(n)))
+            out.append((int(p.value or 0), int(n.value)))
+        return out
+
+    def adopt_from(self, other: "Renderer"):
+        """The scene of another context of this process, copied device to device (no host work, no build)."""
+        self._check(lib().rt_adopt_scene_from(self._ctx, other._ctx))
+        self.width, self.height = other.width, other.height
 
     @property
     def local_tiles(self) -> int:

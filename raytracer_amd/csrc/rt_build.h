@@ -13,6 +13,7 @@ struct BuildGroup {
     int item_base;     // first item of the group in the build's item arrays
     int node_base;     // absolute index of the group's root in the node array
     int n, depth;
+    int wide_base;     // first of the group's records in the array the walk reads (rt_build_wide_records)
 };
 
 inline int rt_build_depth(long long n) {
@@ -31,6 +32,18 @@ hipError_t rt_build_scene_bounds(hipStream_t s, const DevPrimSet& set, float out
 // motion).  Synchronises the stream.
 hipError_t rt_build_hierarchies(hipStream_t s, const DevPrimSet& set, const BuildGroup* groups, int n_groups, long long n_items,
                                 double sphere_e, bool motion, float4* nodes, int* entries, float final6[6]);
+
+// Records of the walk (sub_trace) a group of `depth` needs: (4^ceil(depth / 2) - 1) / 3 for every second level of its
+// binary tree, and one per run.
+inline long long rt_wide_records(int depth) { return ((1ll << (2 * ((depth + 1) >> 1))) - 1) / 3 + (1ll << depth); }
+
+// The records the walk reads: a 4-ary view of the finished binary trees of `groups` in `nodes` (layout of
+// rt_build_hierarchies, or of the host builder: 4 words per node) followed, per group, by one record per run with the
+// boxes of the run's own primitives (of `set`, which the final `entries` index), the entries and their places in the
+// reference's testing order (`order`, or NULL: the entries themselves).  Written to `wide` at 8 (motion: 16) words per
+// record from every group's wide_base.  Synchronises the stream.
+hipError_t rt_build_wide_records(hipStream_t s, const DevPrimSet& set, const BuildGroup* groups, int n_groups, bool motion, double sphere_e,
+                                 const float4* nodes, const int* entries, const int* order, float4* wide);
 
 // Records in hierarchy order.  `entries` / `order` = the slot arrays (absolute slots, a group's start at 4 * node_base):
 // on return entries[slot] names the primitive's new place, class << 30 | index into out_planes / out_cubes / out_spheres

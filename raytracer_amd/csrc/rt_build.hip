@@ -21,6 +21,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -366,6 +367,80 @@ __global__ __launch_bounds__(256) void k_motion_deltas(const BuildGroup* __restr
     }
 }
 
+// What the walk reads (sub_trace in rt_kernels.hip), made from the finished binary trees.  blockIdx.y = group; one thread
+// per record; a group's records start at its wide_base.
+//  * Records 0 .. n_rec - 1, n_rec = (4^ceil(depth / 2) - 1) / 3: record c stands for the binary node of level 2j at
+//    place i inside that level, c = (4^j - 1) / 3 + i, and holds, plane by plane, the boxes of that node's four
+//    grandchildren - which the binary records of its two children hold, two each - or, at the bottom of a tree of odd
+//    depth, of its two children (its own binary record), with two boxes nothing can enter in the unused places.
+//  * Records n_rec + r: run r of the group, holding the boxes of the run's own primitives (true bounds, enlarged like
+//    every box of the hierarchy), their entries and their places in the reference's testing order.
+//   words 0-2: min x / y / z of children 0..3   words 3-5: max x / y / z
+//   word 6: the four entries of a run (class << 30 | index in the set, -1 = unused)   word 7: their testing-order keys
+//   MOTION: words 8-13 the planes' change until time 1, words 14-15 unused
+template <bool MOTION>
+__global__ __launch_bounds__(256) void k_wide_records(DevPrimSet S, const BuildGroup* __restrict__ groups, double sphere_e, const float4* __restrict__ nodes,
+                                                      const int* __restrict__ entries, const int* __restrict__ order, float4* __restrict__ wide) {
+    constexpr int W = MOTION ? 16 : 8;
+    const BuildGroup g = groups[blockIdx.y];
+    const int levels = (g.depth + 1) >> 1;
+    const long long n_rec = ((1ll << (2 * levels)) - 1) / 3, n_all = n_rec + (1ll << g.depth);
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n_all; c += (long long)gridDim.x * blockDim.x) {
+        float4 mn[4], mx[4], dmn[4], dmx[4];
+        float4 w6 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), w7 = w6;
+        for (int k = 0; k < 4; ++k) {
+            mn[k] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.0f); mx[k] = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.0f);
+            dmn[k] = dmx[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        if (c >= n_rec) {
+            const size_t slot0 = 4 * ((size_t)g.node_base + (size_t)(c - n_rec));
+            int ev[4], ov[4];
+            for (int k = 0; k < 4; ++k) {
+                ev[k] = entries[slot0 + k]; ov[k] = order ? order[slot0 + k] : ev[k];
+                if (ev[k] == -1) continue;
+                DBox sw, t0, t1;
+                prim_boxes(S, (unsigned)ev[k], sphere_e, sw, MOTION ? &t0 : nullptr, MOTION ? &t1 : nullptr);
+                if (MOTION) {
+                    mn[k] = make_float4(t0.mn[0], t0.mn[1], t0.mn[2], 0.0f); mx[k] = make_float4(t0.mx[0], t0.mx[1], t0.mx[2], 0.0f);
+                    dmn[k] = make_float4(t1.mn[0] - t0.mn[0], t1.mn[1] - t0.mn[1], t1.mn[2] - t0.mn[2], 0.0f);
+                    dmx[k] = make_float4(t1.mx[0] - t0.mx[0], t1.mx[1] - t0.mx[1], t1.mx[2] - t0.mx[2], 0.0f);
+                } else {
+                    mn[k] = make_float4(sw.mn[0], sw.mn[1], sw.mn[2], 0.0f); mx[k] = make_float4(sw.mx[0], sw.mx[1], sw.mx[2], 0.0f);
+                }
+            }
+            w6 = make_float4(i2f(ev[0]), i2f(ev[1]), i2f(ev[2]), i2f(ev[3]));
+            w7 = make_float4(i2f(ov[0]), i2f(ov[1]), i2f(ov[2]), i2f(ov[3]));
+        } else {
+            int j = 0;
+            while (((1ll << (2 * (j + 1))) - 1) / 3 <= c) ++j;
+            const long long i = c - ((1ll << (2 * j)) - 1) / 3;
+            const long long h = (1ll << (2 * j)) - 1 + i;                 // the binary node
+            if (2 * j + 2 <= g.depth) {
+                for (int side = 0; side < 2; ++side) {
+                    const float4* cd = node_words<MOTION>(const_cast<float4*>(nodes), g.node_base, 2 * h + 1 + side);
+                    mn[2 * side] = cd[0]; mx[2 * side] = cd[1]; mn[2 * side + 1] = cd[2]; mx[2 * side + 1] = cd[3];
+                    if (MOTION) { dmn[2 * side] = cd[8]; dmx[2 * side] = cd[9]; dmn[2 * side + 1] = cd[10]; dmx[2 * side + 1] = cd[11]; }
+                }
+            } else {
+                const float4* cd = node_words<MOTION>(const_cast<float4*>(nodes), g.node_base, h);
+                mn[0] = cd[0]; mx[0] = cd[1]; mn[1] = cd[2]; mx[1] = cd[3];
+                if (MOTION) { dmn[0] = cd[8]; dmx[0] = cd[9]; dmn[1] = cd[10]; dmx[1] = cd[11]; }
+            }
+        }
+        float4* out = wide + (size_t)W * ((size_t)g.wide_base + (size_t)c);
+        out[0] = make_float4(mn[0].x, mn[1].x, mn[2].x, mn[3].x); out[1] = make_float4(mn[0].y, mn[1].y, mn[2].y, mn[3].y);
+        out[2] = make_float4(mn[0].z, mn[1].z, mn[2].z, mn[3].z); out[3] = make_float4(mx[0].x, mx[1].x, mx[2].x, mx[3].x);
+        out[4] = make_float4(mx[0].y, mx[1].y, mx[2].y, mx[3].y); out[5] = make_float4(mx[0].z, mx[1].z, mx[2].z, mx[3].z);
+        out[6] = w6; out[7] = w7;
+        if (MOTION) {
+            out[8] = make_float4(dmn[0].x, dmn[1].x, dmn[2].x, dmn[3].x); out[9] = make_float4(dmn[0].y, dmn[1].y, dmn[2].y, dmn[3].y);
+            out[10] = make_float4(dmn[0].z, dmn[1].z, dmn[2].z, dmn[3].z); out[11] = make_float4(dmx[0].x, dmx[1].x, dmx[2].x, dmx[3].x);
+            out[12] = make_float4(dmx[0].y, dmx[1].y, dmx[2].y, dmx[3].y); out[13] = make_float4(dmx[0].z, dmx[1].z, dmx[2].z, dmx[3].z);
+            out[14] = out[15] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
+}
+
 // blockIdx.y = leaf: copy the leaf's primitive records from the file-order arrays.  A leaf's planes take their
 // offset vertex from the file-order first vertex (kept in the spare lanes of the file record's third word).
 __global__ __launch_bounds__(256) void k_gather_leaves(DevPrimSet F, const int* __restrict__ ids, const LeafGather* __restrict__ leaves,
@@ -544,6 +619,23 @@ hipError_t rt_build_hierarchies(hipStream_t s, const DevPrimSet& set, const Buil
     if (final6) BUILD_TRY(hipMemcpyAsync(red, d_red, sizeof red, hipMemcpyDeviceToHost, s));
     BUILD_TRY(hipStreamSynchronize(s));
     if (final6) for (int i = 0; i < 6; ++i) final6[i] = dec_ordered(red[i]);
+    return hipSuccess;
+}
+
+hipError_t rt_build_wide_records(hipStream_t s, const DevPrimSet& set, const BuildGroup* groups, int n_groups, bool motion, double sphere_e,
+                                 const float4* nodes, const int* entries, const int* order, float4* wide) {
+    if (n_groups <= 0) return hipSuccess;
+    if (n_groups > 65535) return hipErrorInvalidValue;
+    int max_depth = 1;
+    for (int g = 0; g < n_groups; ++g) max_depth = groups[g].depth > max_depth ? groups[g].depth : max_depth;
+    Scratch sc; BuildGroup* d_groups;
+    BUILD_TRY(sc.get(&d_groups, (size_t)n_groups));
+    BUILD_TRY(hipMemcpyAsync(d_groups, groups, sizeof(BuildGroup) * (size_t)n_groups, hipMemcpyHostToDevice, s));
+    const long long most = rt_wide_records(max_depth);
+    if (motion) hipLaunchKernelGGL(k_wide_records<true>, dim3(grid_for(most), n_groups), dim3(256), 0, s, set, d_groups, sphere_e, nodes, entries, order, wide);
+    else hipLaunchKernelGGL(k_wide_records<false>, dim3(grid_for(most), n_groups), dim3(256), 0, s, set, d_groups, sphere_e, nodes, entries, order, wide);
+    BUILD_TRY(hipGetLastError());
+    BUILD_TRY(hipStreamSynchronize(s));
     return hipSuccess;
 }
 

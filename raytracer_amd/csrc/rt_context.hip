@@ -236,6 +236,7 @@ struct rt_ctx {
     long long n_file_nodes = 0, n_file_entries = 0;
     int file_sub_depth = 0;                  // depth of the file-order hierarchy
     double sphere_e = 0.0;                   // rounding allowance of the float sphere test, see rt_upload_scene
+    DevBuf<float4> d_sub_wide;                      // what the walk reads: 4-ary records made from the binary trees below (rt_build_wide_records)
     DevBuf<float4> d_sub_nodes_file, d_sub_nodes;   // file-order set alone / file-order set followed by the leaves'
     DevBuf<int> d_sub_entries_file, d_sub_entries, d_prim_ids;
     DevBuf<int> d_sub_order_file, d_sub_order;      // per entry slot: the primitive's place in the reference's testing order
@@ -246,6 +247,13 @@ struct rt_ctx {
     DevBuf<int4> d_leaves, d_tex_desc;
     DevBuf<float4> d_file_planes, d_file_cubes, d_file_spheres, d_leaf_planes, d_leaf_cubes, d_leaf_spheres;
     DevScene scene{};
+
+    // what export / adopt of the device-resident scene need beyond DevScene (rt_export_scene_layout)
+    long long n_textures = 0, n_texels = 0, total_sub_nodes = 0, total_sub_entries = 0, total_wide = 0;
+    int file_wide_base = -1;                             // first record of the file-order set's hierarchy in d_sub_wide, or -1
+    bool adopted = false;                                // the scene's arrays were received from another context, not uploaded
+    std::vector<DevBuf<unsigned char>> adopted_arrays;   // ... and live here
+    std::vector<std::pair<const void*, size_t>> export_arrays;   // distinct arrays of the last export, in order
 
     // sharding
     int rank = 0, world = 1;
@@ -348,12 +356,14 @@ void rt_destroy(rt_ctx* c) {
                               &c->d_file_cubes, &c->d_file_spheres, &c->d_leaf_planes, &c->d_leaf_cubes, &c->d_leaf_spheres,
                               &c->q_a[0], &c->q_a[1], &c->q_b[0], &c->q_b[1], &c->n_a, &c->n_b, &c->n_c, &c->n_col, &c->accum };
     for (auto* b : f4s) b->release();
+    c->d_sub_wide.release();
     c->d_sub_nodes.release(); c->d_sub_entries.release(); c->d_sub_nodes_file.release(); c->d_sub_entries_file.release(); c->d_prim_ids.release();
     for (int k = 0; k < 2; ++k) { c->sort_keys[k].release(); c->sort_slots[k].release(); }
     c->sort_temp.release();
     c->d_sub_order_file.release(); c->d_sub_order.release(); c->d_walk_planes.release(); c->d_walk_cubes.release(); c->d_walk_spheres.release();
     c->d_leaves.release(); c->d_tex_desc.release(); c->d_local_tiles.release(); c->n_uv.release(); c->n_pix.release();
     c->link.release(); c->ctr.release(); c->shadow.release(); c->stats.release(); c->out_tmp.release();
+    for (auto& b : c->adopted_arrays) b.release();
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     c->drop_graphs();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -418,6 +428,31 @@ int rt_synchronize(rt_ctx* c) {
     RT_HIP(c, hipStreamSynchronize(c->stream));
     release_scratch(c);                             // frames of rt_render_device_noalloc are complete: the GPU's scratch array is free again
     if (flag) return c->fail(RT_ERR_CAPACITY, "a work buffer overflowed during a frame; its image is incomplete");
+    return RT_OK;
+}
+
+// The records the walk reads (rt_build_wide_records), made from the finished binary trees in `binary`, the final entry
+// slots and their testing-order keys: the file-order set's group (when it has a hierarchy) first, then the leaves' groups.
+// Assigns every group its wide_base; *file_wide_base receives the file-order group's.
+static int make_wide_records(rt_ctx* c, std::vector<BuildGroup>& leaf_groups, const DevPrimSet& leafset, const float4* binary, const int* entries, const int* order) {
+    const size_t words = c->sub_stride == 8 ? 16 : 8;
+    std::vector<BuildGroup> file_group;
+    long long total = 0;
+    if (c->file_sub_root >= 0) {
+        BuildGroup g{}; g.pn = c->np; g.cn = c->nc; g.sn = c->ns; g.n = c->np + c->nc + c->ns; g.depth = c->file_sub_depth; g.node_base = c->file_sub_root;
+        g.wide_base = 0; total = rt_wide_records(g.depth);
+        file_group.push_back(g);
+    }
+    c->file_wide_base = file_group.empty() ? -1 : 0;
+    for (BuildGroup& g : leaf_groups) { g.wide_base = (int)total; total += rt_wide_records(g.depth); }
+    // the walk addresses a record by a 32-bit byte offset
+    if ((unsigned long long)total * words * 16ull >= (1ull << 32))
+        return c->fail(RT_ERR_CAPACITY, "second-level hierarchies of %lld records exceed the 4 GiB the walk can address", total);
+    c->total_wide = total;
+    RT_HIP(c, c->d_sub_wide.resize((size_t)std::max<long long>(total, 1) * words));
+    const bool motion = c->sub_stride == 8;
+    RT_HIP(c, rt_build_wide_records(c->stream, c->scene.walkset, file_group.data(), (int)file_group.size(), motion, c->sphere_e, binary, entries, order, c->d_sub_wide.p));
+    RT_HIP(c, rt_build_wide_records(c->stream, leafset, leaf_groups.data(), (int)leaf_groups.size(), motion, c->sphere_e, binary, entries, order, c->d_sub_wide.p));
     return RT_OK;
 }
 
@@ -603,6 +638,9 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
     RT_HIP(c, c->d_tex_desc.upload(tex_desc, s));
     RT_HIP(c, c->d_texels.upload(texels, s));
     RT_HIP(c, hipStreamSynchronize(s));             // the host vectors above die with this scope
+    c->n_textures = sc->n_textures; c->n_texels = (long long)texels.size();
+    c->adopted = false; for (auto& b : c->adopted_arrays) b.release();
+    c->adopted_arrays.clear(); c->export_arrays.clear();
 
     DevScene& d = c->scene;
     std::memset(&d, 0, sizeof d);
@@ -697,16 +735,22 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
         if (!(radius < 1e30f)) { radius = 1e30f; for (int k = 0; k < 3; ++k) if (!(std::fabs(centre[k]) < 1e30f)) centre[k] = 0.0f; }
     }
 
+    c->total_wide = 0; c->file_wide_base = -1;
+    if (c->file_sub_root >= 0) {
+        std::vector<BuildGroup> none;
+        RT_TRY(make_wide_records(c, none, d.fileset, c->d_sub_nodes_file.p, c->d_sub_entries_file.p, d.sub_order));
+    }
     d.mats = c->d_mats.p; d.plane_uv = c->d_plane_uv.p; d.plane_bound = c->d_plane_bound.p; d.tex_desc = c->d_tex_desc.p; d.texels = c->d_texels.p;
     d.lights = c->d_lights.p; d.n_lights = sc->n_lights;
-    d.sub_nodes = c->n_file_nodes ? c->d_sub_nodes_file.p : nullptr;
-    d.sub_entries = c->d_sub_entries_file.p; d.file_sub_root = c->file_sub_root;
+    d.sub_nodes = c->n_file_nodes ? c->d_sub_wide.p : nullptr;
+    d.sub_entries = c->d_sub_entries_file.p; d.file_sub_root = c->file_wide_base;
     d.file_sub_depth = c->file_sub_depth; d.sub_stride = c->sub_stride;
     d.sub_stack_entries = d.sub_stack_entries_leaves = rt_sub_stack_entries(c->file_sub_depth);
     d.n_verts = sc->n_plane_verts;
     d.lds_prims = (!d.sub_nodes && rt_lds_prim_words(d) <= RT_LDS_PRIM_MAX_WORDS) ? c->lds_prims : 0;
     for (int k = 0; k < 3; ++k) d.center[k] = centre[k];
     d.radius = radius;
+    c->total_sub_nodes = c->n_file_nodes; c->total_sub_entries = c->n_file_entries;
     c->have_scene = true;
     c->rebuild_tiles();
     RT_HIP(c, c->d_local_tiles.upload(c->local_tiles, s));
@@ -717,16 +761,23 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
 static int upload_bvh_impl(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const int32_t* prim_ids, int32_t n_prim_ids) {
     if (!c) return RT_ERR_ARG;
     if (!c->have_scene) return c->fail(RT_ERR_STATE, "rt_upload_bvh before rt_upload_scene");
+    if (c->adopted) return c->fail(RT_ERR_STATE, "rt_upload_bvh on a context whose scene was adopted from another one: upload the tree there and adopt again");
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->have_bvh = false;
     c->drop_graphs();
     DevScene& d = c->scene;
     d.n_nodes = 0; d.n_leaves = 0;
-    d.sub_nodes = c->n_file_nodes ? c->d_sub_nodes_file.p : nullptr; d.sub_entries = c->d_sub_entries_file.p;
     const bool reordered = d.walkset.cubes != d.fileset.cubes || d.walkset.spheres != d.fileset.spheres || d.walkset.planes != d.fileset.planes;
     d.sub_order = reordered ? c->d_sub_order_file.p : nullptr;
+    c->total_wide = 0;
+    if (c->n_file_nodes && c->file_sub_root >= 0) {      // (a tree uploaded earlier may have left the leaves' records here)
+        std::vector<BuildGroup> none;
+        RT_TRY(make_wide_records(c, none, d.fileset, c->d_sub_nodes_file.p, c->d_sub_entries_file.p, d.sub_order));
+    }
+    d.sub_nodes = c->n_file_nodes ? c->d_sub_wide.p : nullptr; d.sub_entries = c->d_sub_entries_file.p; d.file_sub_root = c->file_wide_base;
     d.sub_stack_entries = d.sub_stack_entries_leaves = rt_sub_stack_entries(c->file_sub_depth);
+    c->total_sub_nodes = c->n_file_nodes; c->total_sub_entries = c->n_file_entries; c->export_arrays.clear();
     int deepest = c->file_sub_depth, deepest_leaf = 0;
     if (!nodes || n_nodes <= 0) return RT_OK;
     if (n_prim_ids < 0 || (n_prim_ids && !prim_ids)) return c->fail(RT_ERR_ARG, "bad prim_ids");
@@ -914,7 +965,19 @@ static int upload_bvh_impl(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes,
     RT_HIP(c, c->d_nodes.upload(dn, s));
     RT_HIP(c, c->d_leaves.upload(leaves, s));
     RT_HIP(c, hipStreamSynchronize(s));
-    d.sub_nodes = total_nodes ? c->d_sub_nodes.p : nullptr; d.sub_entries = c->d_sub_entries.p;
+    if (total_nodes) {
+        RT_TRY(make_wide_records(c, groups, leafset, c->d_sub_nodes.p, c->d_sub_entries.p, d.sub_order));
+        // a leaf's record names its hierarchy by the first of its records
+        size_t gi = 0;
+        for (size_t g = 0; g < gather.size() && gi < groups.size(); ++g)
+            if (leaves[2 * g + 1].z == groups[gi].node_base && leaves[2 * g + 1].w == groups[gi].depth) { leaves[2 * g + 1].z = groups[gi].wide_base; ++gi; }
+        if (gi != groups.size()) return c->fail(RT_ERR_STATE, "rt_upload_bvh: leaves and their hierarchies out of step");
+        RT_HIP(c, c->d_leaves.upload(leaves, s));
+        RT_HIP(c, hipStreamSynchronize(s));
+        c->d_sub_nodes.release();                     // the binary trees of file-order set + leaves: only the records are read from here on
+    }
+    d.sub_nodes = total_nodes ? c->d_sub_wide.p : nullptr; d.sub_entries = c->d_sub_entries.p; d.file_sub_root = c->file_wide_base;
+    c->total_sub_nodes = total_nodes; c->total_sub_entries = total_entries;
     d.nodes = c->d_nodes.p; d.n_nodes = (int)out.size();
     d.leaves = c->d_leaves.p; d.n_leaves = (int)(leaves.size() / 2);
     d.leafset = leafset;
@@ -936,6 +999,165 @@ int rt_upload_bvh(rt_ctx* c, const rt_bvh_node* nodes, int32_t n_nodes, const in
     try { return upload_bvh_impl(c, nodes, n_nodes, prim_ids, n_prim_ids); }
     catch (const std::bad_alloc&) { c->have_bvh = false; return c->fail(RT_ERR_ARG, "rt_upload_bvh: out of host memory for a tree of this size"); }
     catch (const std::exception& e) { c->have_bvh = false; return c->fail(RT_ERR_ARG, "rt_upload_bvh: %s", e.what()); }
+}
+
+// ---- the device-resident scene handed from one context to others ----------------------------------------------------
+// After the uploads a context holds, in its GPU's memory, every array the kernels read (first-level nodes, leaf records,
+// the primitive sets in leaf / file / hierarchy order, polygon edges, materials, texels, lights, the second-level
+// hierarchies): DevScene is the table of contents.  Another context - on another GPU of the node, in this process or in
+// another rank's - can take over that scene without parsing, building or uploading anything: it adopts the LAYOUT (a
+// small POD blob: DevScene with array numbers in place of addresses, the counts that size the arrays, the camera) and
+// allocates the arrays; the bytes then travel device to device (ncclBroadcast over xGMI in rt_multi_upload and
+// raytracer_amd/dist.py, plain device copies on one GPU).
+namespace {
+
+struct PtrSlot { const void** p; size_t bytes; };
+
+// every device pointer of a DevScene with the bytes behind it, always in the same order
+void scene_ptr_slots(DevScene& d, long long n_mats, long long n_textures, long long n_texels, long long sub_nodes, long long sub_entries,
+                     std::vector<PtrSlot>& out) {
+    auto add = [&](const void* const& field, size_t bytes) { out.push_back(PtrSlot{ (const void**)&field, bytes }); };
+    add(*(const void**)&d.nodes, (size_t)d.n_nodes * 32); add(*(const void**)&d.leaves, (size_t)d.n_leaves * 32);
+    for (DevPrimSet* S : { &d.leafset, &d.fileset, &d.walkset }) {
+        add(*(const void**)&S->planes, (size_t)S->n_planes * 48); add(*(const void**)&S->verts, (size_t)d.n_verts * 16);
+        add(*(const void**)&S->edges, (size_t)d.n_verts * 16); add(*(const void**)&S->cubes, (size_t)S->n_cubes * 96);
+        add(*(const void**)&S->spheres, (size_t)S->n_spheres * 32);
+    }
+    add(*(const void**)&d.mats, (size_t)n_mats * 48); add(*(const void**)&d.plane_uv, (size_t)d.fileset.n_planes * 48);
+    add(*(const void**)&d.plane_bound, (size_t)d.fileset.n_planes * 16);
+    add(*(const void**)&d.tex_desc, (size_t)n_textures * 16); add(*(const void**)&d.texels, (size_t)n_texels * 16);
+    add(*(const void**)&d.lights, (size_t)d.n_lights * 16);
+    add(*(const void**)&d.sub_nodes, (size_t)sub_nodes * (size_t)(d.sub_stride == 8 ? 16 : 8) * 16);     // the walk's records
+    // (the entry slots and their testing-order keys are build products; the kernels read the copies inside the records)
+    add(*(const void**)&d.sub_entries, 0); add(*(const void**)&d.sub_order, 0); (void)sub_entries;
+}
+
+enum { RT_LAYOUT_MAGIC = 0x52544C31, RT_LAYOUT_MAX_SLOTS = 32 };
+struct SceneLayout {
+    uint32_t magic, bytes;
+    DevScene scene;                                  // pointer fields are meaningless outside the exporting process
+    rt_camera camera;
+    long long np, nc, ns, n_textures, n_texels, sub_nodes, sub_entries;
+    int n_lights, any_reflective, any_transparent, have_bvh, sub_stride, file_sub_depth, n_slots, n_arrays;
+    int slot_array[RT_LAYOUT_MAX_SLOTS];             // per pointer slot: which array it points into, or -1 (null / nothing behind it)
+    unsigned long long array_bytes[RT_LAYOUT_MAX_SLOTS];
+};
+
+} // namespace
+
+uint64_t rt_scene_layout_bytes(void) { return sizeof(SceneLayout); }
+
+int rt_export_scene_layout(rt_ctx* c, void* layout, uint64_t cap) {
+    if (!c || !layout) return RT_ERR_ARG;
+    if (!c->have_scene) return c->fail(RT_ERR_STATE, "rt_export_scene_layout before rt_upload_scene");
+    if (cap < sizeof(SceneLayout)) return c->fail(RT_ERR_ARG, "layout buffer of %llu bytes, %zu needed", (unsigned long long)cap, sizeof(SceneLayout));
+    SceneLayout L; std::memset(&L, 0, sizeof L);
+    L.magic = RT_LAYOUT_MAGIC; L.bytes = (uint32_t)sizeof L;
+    L.scene = c->scene; L.scene.walk_stats = nullptr; L.camera = c->camera;
+    L.np = c->np; L.nc = c->nc; L.ns = c->ns; L.n_textures = c->n_textures; L.n_texels = c->n_texels;
+    L.sub_nodes = c->total_wide; L.sub_entries = c->total_sub_entries;
+    L.n_lights = c->n_lights; L.any_reflective = c->any_reflective; L.any_transparent = c->any_transparent; L.have_bvh = c->have_bvh;
+    L.sub_stride = c->sub_stride; L.file_sub_depth = c->file_sub_depth;
+    std::vector<PtrSlot> slots;
+    scene_ptr_slots(L.scene, (long long)c->np + c->nc + c->ns, L.n_textures, L.n_texels, L.sub_nodes, L.sub_entries, slots);
+    if (slots.size() > RT_LAYOUT_MAX_SLOTS) return c->fail(RT_ERR_STATE, "layout table too small");
+    L.n_slots = (int)slots.size();
+    c->export_arrays.clear();
+    for (size_t k = 0; k < slots.size(); ++k) {
+        const void* ptr = *slots[k].p;
+        L.slot_array[k] = -1;
+        if (!ptr || !slots[k].bytes) continue;
+        size_t a = 0;
+        for (; a < c->export_arrays.size(); ++a) if (c->export_arrays[a].first == ptr) break;
+        if (a == c->export_arrays.size()) c->export_arrays.push_back({ ptr, slots[k].bytes });
+        else c->export_arrays[a].second = std::max(c->export_arrays[a].second, slots[k].bytes);
+        L.slot_array[k] = (int)a;
+    }
+    L.n_arrays = (int)c->export_arrays.size();
+    for (int a = 0; a < L.n_arrays; ++a) L.array_bytes[a] = c->export_arrays[(size_t)a].second;
+    for (auto& sl : slots) *sl.p = nullptr;          // no address leaves the process
+    std::memcpy(layout, &L, sizeof L);
+    return RT_OK;
+}
+
+static int adopt_layout_impl(rt_ctx* c, const void* layout, uint64_t bytes) {
+    if (!c || !layout) return RT_ERR_ARG;
+    SceneLayout L;
+    if (bytes < sizeof L) return c->fail(RT_ERR_ARG, "scene layout of %llu bytes, %zu expected", (unsigned long long)bytes, sizeof L);
+    std::memcpy(&L, layout, sizeof L);
+    if (L.magic != RT_LAYOUT_MAGIC || L.bytes != sizeof L) return c->fail(RT_ERR_ARG, "not a scene layout of this library version");
+    if (L.n_slots < 0 || L.n_slots > RT_LAYOUT_MAX_SLOTS || L.n_arrays < 0 || L.n_arrays > L.n_slots) return c->fail(RT_ERR_ARG, "scene layout: bad table");
+    std::vector<PtrSlot> slots;
+    scene_ptr_slots(L.scene, L.np + L.nc + L.ns, L.n_textures, L.n_texels, L.sub_nodes, L.sub_entries, slots);
+    if ((int)slots.size() != L.n_slots) return c->fail(RT_ERR_ARG, "scene layout: %d pointer slots, %zu expected", L.n_slots, slots.size());
+    for (int k = 0; k < L.n_slots; ++k) {
+        const int a = L.slot_array[k];
+        if (a < -1 || a >= L.n_arrays) return c->fail(RT_ERR_ARG, "scene layout: slot %d names array %d of %d", k, a, L.n_arrays);
+        if (a >= 0 && slots[(size_t)k].bytes > L.array_bytes[a]) return c->fail(RT_ERR_ARG, "scene layout: slot %d needs %zu bytes, its array has %llu", k, slots[(size_t)k].bytes, L.array_bytes[a]);
+    }
+    if (!(L.camera.res_x >= 1.0f && L.camera.res_y >= 1.0f && L.camera.res_x <= 65536.0f && L.camera.res_y <= 65536.0f))
+        return c->fail(RT_ERR_ARG, "scene layout: film resolution out of range");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));     // previous frames may still read the old arrays
+    c->drop_graphs();
+    c->have_scene = false; c->have_bvh = false; c->adopted = false;
+    for (auto& b : c->adopted_arrays) b.release();
+    c->adopted_arrays.clear(); c->export_arrays.clear();
+    c->adopted_arrays.resize((size_t)L.n_arrays);
+    for (int a = 0; a < L.n_arrays; ++a) RT_HIP(c, c->adopted_arrays[(size_t)a].resize((size_t)L.array_bytes[a]));
+    for (int k = 0; k < L.n_slots; ++k) *slots[(size_t)k].p = L.slot_array[k] >= 0 ? c->adopted_arrays[(size_t)L.slot_array[k]].p : nullptr;
+    c->scene = L.scene; c->scene.walk_stats = nullptr;
+    c->camera = L.camera; c->np = (int)L.np; c->nc = (int)L.nc; c->ns = (int)L.ns; c->n_lights = L.n_lights;
+    c->n_textures = L.n_textures; c->n_texels = L.n_texels; c->total_wide = L.sub_nodes; c->total_sub_nodes = 0; c->total_sub_entries = L.sub_entries;
+    c->any_reflective = L.any_reflective != 0; c->any_transparent = L.any_transparent != 0;
+    c->sub_stride = L.sub_stride; c->file_sub_depth = L.file_sub_depth;
+    // the uploads' host-side copies do not exist here: a tree can only arrive with the next adoption
+    c->h_file_planes.clear(); c->h_file_cubes.clear(); c->h_file_spheres.clear(); c->h_verts_sorted.clear(); c->h_edges.clear();
+    c->tb_planes.clear(); c->tb_cubes.clear(); c->tb_spheres.clear(); c->h_sub_nodes_file.clear(); c->h_sub_entries_file.clear();
+    c->adopted = true; c->have_scene = true; c->have_bvh = L.have_bvh != 0;
+    c->rebuild_tiles();
+    RT_HIP(c, c->d_local_tiles.upload(c->local_tiles, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_adopt_scene_layout(rt_ctx* c, const void* layout, uint64_t bytes) {
+    try { return adopt_layout_impl(c, layout, bytes); }
+    catch (const std::exception& e) { if (c) { c->have_scene = false; return c->fail(RT_ERR_ARG, "rt_adopt_scene_layout: %s", e.what()); } return RT_ERR_ARG; }
+}
+
+int rt_scene_layout_resolution(const void* layout, uint64_t bytes, int32_t* width, int32_t* height) {
+    SceneLayout L;
+    if (!layout || !width || !height || bytes < sizeof L) return RT_ERR_ARG;
+    std::memcpy(&L, layout, sizeof L);
+    if (L.magic != RT_LAYOUT_MAGIC || L.bytes != sizeof L) return RT_ERR_ARG;
+    *width = (int32_t)L.camera.res_x; *height = (int32_t)L.camera.res_y;
+    return RT_OK;
+}
+
+int32_t rt_scene_array_count(const rt_ctx* c) {
+    if (!c || !c->have_scene) return 0;
+    return (int32_t)(c->adopted ? c->adopted_arrays.size() : c->export_arrays.size());
+}
+
+int rt_scene_array(rt_ctx* c, int32_t k, void** dev_ptr, uint64_t* bytes) {
+    if (!c || !dev_ptr || !bytes) return RT_ERR_ARG;
+    if (k < 0 || k >= rt_scene_array_count(c)) return c->fail(RT_ERR_ARG, "scene array %d of %d (export or adopt a layout first)", k, rt_scene_array_count(c));
+    if (c->adopted) { *dev_ptr = c->adopted_arrays[(size_t)k].p; *bytes = c->adopted_arrays[(size_t)k].n; }
+    else { *dev_ptr = const_cast<void*>(c->export_arrays[(size_t)k].first); *bytes = c->export_arrays[(size_t)k].second; }
+    return RT_OK;
+}
+
+int rt_adopt_scene_from(rt_ctx* dst, rt_ctx* src) {
+    if (!dst || !src || dst == src) return RT_ERR_ARG;
+    std::vector<unsigned char> blob(sizeof(SceneLayout));
+    if (rt_export_scene_layout(src, blob.data(), blob.size()) != RT_OK) return dst->fail(RT_ERR_STATE, "source context: %s", src->err.c_str());
+    RT_TRY(rt_adopt_scene_layout(dst, blob.data(), blob.size()));
+    RT_HIP(dst, hipSetDevice(dst->device));
+    for (size_t a = 0; a < dst->adopted_arrays.size(); ++a)
+        RT_HIP(dst, hipMemcpyAsync(dst->adopted_arrays[a].p, src->export_arrays[a].first, src->export_arrays[a].second, hipMemcpyDefault, dst->stream));
+    RT_HIP(dst, hipStreamSynchronize(dst->stream));
+    return RT_OK;
 }
 
 int rt_set_shard(rt_ctx* c, int32_t rank, int32_t world) {

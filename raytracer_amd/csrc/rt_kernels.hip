@@ -42,13 +42,13 @@ enum { WS_BOX = 0, WS_GROUP = 1, WS_STEP = 2, WS_PLANE = 3, WS_CUBE = 4, WS_CUBE
 #define RT_EXTEND_WAVES 4           // scenes without second-level hierarchies: a few spills, better co-residency
 #endif
 #ifndef RT_EXTEND_WAVES_SUB
-#define RT_EXTEND_WAVES_SUB 4       // the hierarchy walk is latency-bound: a fourth wavefront beats the spills it costs
+#define RT_EXTEND_WAVES_SUB 3       // 168 registers: the walk plus the hit's shading state fit almost without spills (4: 45-85 spilled, 10 % slower; 5: 30 % slower)
 #endif
 #ifndef RT_SHADOW_WAVES
 #define RT_SHADOW_WAVES 5           // each mode's kernel fits 96 registers without spilling
 #endif
 #ifndef RT_SHADOW_WAVES_SUB
-#define RT_SHADOW_WAVES_SUB 4
+#define RT_SHADOW_WAVES_SUB 3       // no spills at 132-144 registers
 #endif
 
 #ifndef M_PI
@@ -404,40 +404,51 @@ DEVI bool test_prims(const DevPrimSet& S, const Ray& r, bool mb, int p0, int pn,
 // Second-level hierarchy.  The reference's tree stops at depth 8, so a leaf of a large scene holds thousands of
 // primitives, and its leaf rule (and the brute-force rule) is "closest reported distance, the earlier primitive
 // wins an exact tie".  That result does not depend on the order of testing, so groups of more than a few
-// primitives get a conventional binary BVH over their TRUE bounds, walked front to back with an LDS stack:
+// primitives get a conventional BVH over their TRUE bounds, walked front to back with an LDS stack:
 //   * a candidate replaces the best one if it is nearer, or exactly as near and earlier in the reference's
-//     testing order (planes, cubes, spheres; file order inside a class) - the packed entry is that order;
+//     testing order (planes, cubes, spheres; file order inside a class) - every run's record keeps that order per entry;
 //   * a subtree is skipped only when the ray provably cannot report a hit in it that would win: its box,
 //     enlarged by `pad`, is missed or entered beyond the best distance, all with slack for rounding.  `pad`
 //     covers what a primitive test may report outside the primitive's true bounds (a cube test treats a
 //     direction component below 1e-5 as zero, which moves the reported point by up to 1e-5 x distance).
-// An interior node holds both children's boxes: (minL, refL) (maxL, cntL) (minR, refR) (maxR, cntR); ref >= 0 is an
-// interior node, ref < 0 a run of cnt entries starting at ~ref (a multiple of four).  entry = class << 30 | index in the set.
-// In scenes with moving primitives those are the boxes at time 0, and four more words per node hold how far each corner
-// moves until time 1: primitives move on straight lines, so the interpolated box bounds them at the ray's time.
+// The builders make a perfect binary tree per group (rt_build.hip); what the walk reads is a 4-ary view of it
+// (rt_build_wide_records): one record per node of every SECOND binary level, holding the boxes of that node's four
+// grandchildren (or, at the bottom of a tree of odd depth, of its two children) plane by plane:
+//   words 0-2 = min x / y / z of children 0..3, words 3-5 = max x / y / z of children 0..3      (128 bytes, one cache line)
+// and, in scenes with moving primitives, words 8-13 = how far each of those planes moves until time 1 (256 bytes):
+// primitives move on straight lines, so the interpolated box bounds them at the ray's time.  Records are numbered as a
+// 4-ary heap per group (record c of the group sits at root + c, its children at 4c + 1 .. 4c + 4; the children of the
+// last level are runs of up to RT_SUB_LEAF entries, run j of the group owning the entry slots 4 * (root + j) .. + 3).
 // ---------------------------------------------------------------------------------------------------------
 // Per-ray constants of the second-level walk.  A box is entered at max over axes of (near plane - origin) / d and left
-// at min over axes of (far plane - origin) / d; which plane is the near one depends only on the sign of d, and with
-// the reciprocal and the products origin * reciprocal formed once per ray a plane costs one select and one fused
-// multiply-add.  The origin is moved by `pad` away from the box on either side (what a primitive test may report
-// outside the primitive's true bounds), and the constants carry the slack for the rounding of this arithmetic (the
-// reciprocal is good to 1 ulp and the two products cancel when the origin lies near a plane), so that a box is only
-// ever skipped when the exact arithmetic would skip it too.
-struct SubRay { V3 rcp, cn, cf; bool px, py, pz; };
+// at min over axes of (far plane - origin) / d.  Which plane is the near one depends only on the sign of d, so the ray
+// keeps, per axis, the BYTE OFFSET of its near and of its far plane word inside a record and loads exactly those: no
+// select per box.  With the reciprocal and the products origin * reciprocal formed once per ray, a plane of four
+// children costs four fused multiply-adds.  Conservative by construction, so that a box is only ever skipped when the
+// exact arithmetic would skip it too:
+//   * the origin is moved by `pad` away from the box on either side (what a primitive test may report outside the
+//     primitive's true bounds);
+//   * the near reciprocal is scaled by 1 - 4e-6 and the far one by 1 + 4e-6 (positive entry distances shrink, positive
+//     exit distances grow, by more than the rounding of the reciprocal and of the multiply-add; negative ones only
+//     matter through their sign, which scaling keeps);
+//   * the constants carry 1e-6 of their own magnitude (the two products cancel when the origin lies near a plane).
+struct SubRay { V3 rn, rf, cn, cf; unsigned on_x, on_y, on_z, of_x, of_y, of_z; };
 
-DEVI void sub_axis(float o, float d, float pad, float& rcp, float& cn, float& cf, bool& pos) {
-    pos = d >= 0.0f;
+DEVI void sub_axis(float o, float d, float pad, unsigned off_min, unsigned off_max, float& rn, float& rf, float& cn, float& cf, unsigned& on, unsigned& of) {
+    const bool pos = d >= 0.0f;
+    on = pos ? off_min : off_max; of = pos ? off_max : off_min;
     if (fabsf(d) > 1e-12f) {
-        rcp = __builtin_amdgcn_rcpf(d);
+        const float rcp = __builtin_amdgcn_rcpf(d);
+        rn = rcp * 0.999996f; rf = rcp * 1.000004f;
         // d > 0: entered through the min plane, seen from origin + pad; left through the max plane, from origin - pad
-        const float on = pos ? o + pad : o - pad, of = pos ? o - pad : o + pad;
-        cn = -on * rcp; cf = -of * rcp;
+        const float o_n = pos ? o + pad : o - pad, o_f = pos ? o - pad : o + pad;
+        cn = -o_n * rn; cf = -o_f * rf;
         cn -= 1e-6f * fabsf(cn) + 1e-30f; cf += 1e-6f * fabsf(cf) + 1e-30f;
-        if (!(cn == cn) || !(cf == cf)) { rcp = 0.0f; cn = -INFINITY; cf = INFINITY; }     // NaN origin or pad: no constraint
+        if (!(cn == cn) || !(cf == cf)) { rn = rf = 0.0f; cn = -INFINITY; cf = INFINITY; }     // NaN origin or pad: no constraint
     } else {
         // zero, denormal-small or NaN component: this axis constrains nothing (a ray parallel to the slab and outside it
         // is then visited needlessly, never skipped wrongly)
-        rcp = 0.0f; cn = -INFINITY; cf = INFINITY;
+        rn = rf = 0.0f; cn = -INFINITY; cf = INFINITY;
     }
 }
 
@@ -446,42 +457,21 @@ DEVI SubRay make_sub_ray(const DevScene& sc, const Ray& r) {
     V3 dc = r.o - mk(sc.center[0], sc.center[1], sc.center[2]);
     float pad = 2e-5f * (__builtin_amdgcn_sqrtf(dot(dc, dc)) + sc.radius) + 1e-6f * sc.radius;
     if (!(pad >= 0.0f)) pad = INFINITY;          // NaN origin: nothing may be skipped
-    sub_axis(r.o.x, r.d.x, pad, q.rcp.x, q.cn.x, q.cf.x, q.px);
-    sub_axis(r.o.y, r.d.y, pad, q.rcp.y, q.cn.y, q.cf.y, q.py);
-    sub_axis(r.o.z, r.d.z, pad, q.rcp.z, q.cn.z, q.cf.z, q.pz);
+    sub_axis(r.o.x, r.d.x, pad, 0u, 48u, q.rn.x, q.rf.x, q.cn.x, q.cf.x, q.on_x, q.of_x);
+    sub_axis(r.o.y, r.d.y, pad, 16u, 64u, q.rn.y, q.rf.y, q.cn.y, q.cf.y, q.on_y, q.of_y);
+    sub_axis(r.o.z, r.d.z, pad, 32u, 80u, q.rn.z, q.rf.z, q.cn.z, q.cf.z, q.on_z, q.of_z);
     return q;
 }
 
-// Entry and exit parameter of the ray against a box.  A non-finite bound times a zero reciprocal gives NaN, which fails
-// every comparison of the caller and makes it visit the box.
-DEVI void sub_child(const SubRay& q, float4 mn, float4 mx, float& tn, float& tf) {
-    const float nx = q.px ? mn.x : mx.x, fx = q.px ? mx.x : mn.x;
-    const float ny = q.py ? mn.y : mx.y, fy = q.py ? mx.y : mn.y;
-    const float nz = q.pz ? mn.z : mx.z, fz = q.pz ? mx.z : mn.z;
-    const float n0 = __builtin_fmaf(nx, q.rcp.x, q.cn.x), f0 = __builtin_fmaf(fx, q.rcp.x, q.cf.x);
-    const float n1 = __builtin_fmaf(ny, q.rcp.y, q.cn.y), f1 = __builtin_fmaf(fy, q.rcp.y, q.cf.y);
-    const float n2 = __builtin_fmaf(nz, q.rcp.z, q.cn.z), f2 = __builtin_fmaf(fz, q.rcp.z, q.cf.z);
-    tn = fmaxf(fmaxf(n0, n1), n2);
-    tf = fminf(fminf(f0, f1), f2);
-    const float m = fmaxf(fabsf(tn), fabsf(tf));     // relative slack for the products' own rounding
-    tn = __builtin_fmaf(-1e-6f, m, tn); tf = __builtin_fmaf(1e-6f, m, tf);
-}
+// max / min of three that ignore NaN operands (a non-finite plane times a zero reciprocal): one instruction each
+DEVI float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+DEVI float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 
-// Exact tie between two reported distances: the primitive the reference tests first wins (strict '<' in its loops).
-// sub_order keeps every slot's place in that order; without it the entry itself is the place.  Rarely reached, and kept
-// out of line so that the walk's registers are not held across it.
-__device__ __noinline__ bool tested_earlier(const DevScene& sc, int slot, int best_slot) {
-    const int* __restrict__ ord = sc.sub_order ? sc.sub_order : sc.sub_entries;
-    return (unsigned)ord[slot] < (unsigned)ord[best_slot];
-}
-
-// Layout the walk relies on: a group's hierarchy is a perfect binary tree in heap order (node h of the group sits at
-// root + h, its children at root + 2h + 1 and root + 2h + 2, the levels 0 .. depth - 1 are interior, the children of
-// level depth - 1 are runs), and run j of the group owns the four entry slots 4 * (root + j) .. + 3 (unused slots hold
-// -1).  Siblings are adjacent in memory, so one step can skip a level: instead of the node's own record (the boxes of
-// its two children) it loads the records of both children (128 contiguous bytes, address known from the heap index
-// alone) and tests the four grandchildren - half as many dependent round trips to memory per ray.  All children of a
-// step are of one kind: interior nodes, or (below level depth - 2) runs.
+// Records of a group (rt_build_wide_records): c < n_rec = (4^levels - 1) / 3 are the 4-ary view of the binary tree,
+// levels = ceil(depth / 2); the children of the last of those levels are the group's runs, whose records follow from
+// n_rec: run r at n_rec + r, holding the boxes of its own (up to four) primitives, their entries (word 6) and their
+// places in the reference's testing order (word 7).  So a run is searched like any other node - one load round, four
+// box tests - and only the primitives whose box the ray enters before the best hit so far are tested, nearest box first.
 template <bool ANY, bool FAST, bool MOTION>
 DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth, const Ray& r, const SubRay& q, bool mb, bool leaf_rule,
                     float stop_below, int* __restrict__ stack, Best& best) {
@@ -490,101 +480,100 @@ DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth
     // asks "is the closest distance below stop_below" has a hit at or beyond that value, stop_below itself (nothing
     // entered later than that can change the answer; which primitive is reported is then not the caller's concern)
     float prune_t = best_t;
-    int best_slot = 0; bool has = false;
-    int sp = 0, h = 0;                                        // h = heap index inside the group
-    // Scenes with moving primitives keep boxes per time (8 words per node); rays at time 0 - every secondary ray, and
-    // every ray of a frame without motion blur, where primitives stay at their first location - read the first half only.
+    unsigned best_order = 0; bool has = false;
+    int sp = 0;
+    unsigned c = 0;                                           // record inside the group
+    const int levels = (depth + 1) >> 1;                      // record levels above the runs: a step moves two binary levels down
+    const unsigned n_rec = ((1u << (2 * levels)) - 1u) / 3u;  // first run record
+    const unsigned first_last = ((1u << (2 * (levels - 1))) - 1u) / 3u;     // first record of the last level above the runs
+    const bool pairs = (depth & 1) != 0;                      // odd depth: a record of that level has two runs below it, not four
+    // Scenes with moving primitives keep boxes per time; rays at time 0 - every secondary ray, and every ray of a frame
+    // without motion blur, where primitives stay at their first location - read the first half of a record only.
     const float tm = (MOTION && mb) ? r.time : 0.0f;
-    const float4* __restrict__ base = sc.sub_nodes + (size_t)(MOTION ? 8 : 4) * (size_t)root;
-    const int first_run = (1 << depth) - 1;                   // heap index the first run would have
+    constexpr unsigned REC = MOTION ? 256u : 128u;
+    const char* __restrict__ base = (const char*)sc.sub_nodes;
     for (;;) {
         RT_WS(sc, WS_STEP);
-        const int level = 31 - __clz(h + 1);
-        const bool wide = level + 2 <= depth;                 // the children are interior nodes: step to the grandchildren
-        const bool runs = level + 2 >= depth;                 // what this step tests are runs of entries
-        const int kid0 = wide ? 4 * h + 3 : 2 * h + 1;        // heap index of the first child tested
-        // first word of the record(s) read: node h itself, or (wide) its two children, which are neighbours
-        const int first = wide ? 2 * h + 1 : h;
-        const float4* __restrict__ nd = base + (MOTION ? (unsigned)rt_sub_motion_offset(first) : 4u * (unsigned)first);
-        float4 bx[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) bx[k] = nd[k];
-        if (wide) {
-#pragma unroll
-            for (int k = 4; k < 8; ++k) bx[k] = nd[k];
-        }
+        const unsigned off = ((unsigned)root + c) * REC;      // (the upload keeps every record below 4 GiB)
+        const bool is_run = c >= n_rec;
+        float4 nx = *(const float4*)(base + (off + q.on_x)), ny = *(const float4*)(base + (off + q.on_y)), nz = *(const float4*)(base + (off + q.on_z));
+        float4 fx = *(const float4*)(base + (off + q.of_x)), fy = *(const float4*)(base + (off + q.of_y)), fz = *(const float4*)(base + (off + q.of_z));
+        int4 ev = make_int4(-1, -1, -1, -1);
+        if (is_run) ev = *(const int4*)(base + (off + 96u));
         if (MOTION && tm != 0.0f) {
-            // boxes per time: corners at time 0 plus time x (their change until time 1)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float4 dl = nd[8 + k];
-                bx[k].x = __builtin_fmaf(dl.x, tm, bx[k].x); bx[k].y = __builtin_fmaf(dl.y, tm, bx[k].y); bx[k].z = __builtin_fmaf(dl.z, tm, bx[k].z);
-            }
-            if (wide) {
-#pragma unroll
-                for (int k = 4; k < 8; ++k) {
-                    const float4 dl = nd[8 + k];
-                    bx[k].x = __builtin_fmaf(dl.x, tm, bx[k].x); bx[k].y = __builtin_fmaf(dl.y, tm, bx[k].y); bx[k].z = __builtin_fmaf(dl.z, tm, bx[k].z);
-                }
-            }
+            // boxes per time: planes at time 0 plus time x (their change until time 1)
+            const float4 dnx = *(const float4*)(base + (off + 128u + q.on_x)), dny = *(const float4*)(base + (off + 128u + q.on_y)), dnz = *(const float4*)(base + (off + 128u + q.on_z));
+            const float4 dfx = *(const float4*)(base + (off + 128u + q.of_x)), dfy = *(const float4*)(base + (off + 128u + q.of_y)), dfz = *(const float4*)(base + (off + 128u + q.of_z));
+#define RT_MOVE(p, dp) p.x = __builtin_fmaf(dp.x, tm, p.x); p.y = __builtin_fmaf(dp.y, tm, p.y); p.z = __builtin_fmaf(dp.z, tm, p.z); p.w = __builtin_fmaf(dp.w, tm, p.w)
+            RT_MOVE(nx, dnx); RT_MOVE(ny, dny); RT_MOVE(nz, dnz); RT_MOVE(fx, dfx); RT_MOVE(fy, dfy); RT_MOVE(fz, dfz);
+#undef RT_MOVE
         }
-        float tn4[4]; bool go4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float tn = 0.0f, tf = 0.0f;
-            if (k < 2 || wide) sub_child(q, bx[2 * k], bx[2 * k + 1], tn, tf);
-            // skip only on a certain miss; any NaN makes the comparisons false and the child is visited
-            go4[k] = (k < 2 || wide) && !(tn > tf) && !(tf < 0.0f) && !(tn > prune_t);
-            tn4[k] = tn;
-        }
-        if (runs) {
-            // entry runs are tested on the spot
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (go4[k] && !(tn4[k] > prune_t)) {
-                    RT_WS(sc, WS_RUN);
-                    const int slot0 = 4 * (root + kid0 + k - first_run);
-                    const int4 ev = *(const int4*)(sc.sub_entries + slot0);
-#pragma unroll
-                    for (int e = 0; e < RT_SUB_LEAF; ++e) {
-                        const unsigned entry = (unsigned)(e == 0 ? ev.x : e == 1 ? ev.y : e == 2 ? ev.z : ev.w);
-                        if (entry == 0xffffffffu) break;
-                        const int cls = (int)(entry >> 30), idx = (int)(entry & 0x3fffffffu);
-                        float t; bool ok;
-                        if (cls == 0) { RT_WS(sc, WS_PLANE); ok = plane_test<false, FAST>(S.planes + 3 * idx, S.edges, nullptr, r, false, t, nullptr); }
-                        else if (cls == 1) { RT_WS(sc, WS_CUBE); ok = cube_test<false, FAST>(S.cubes + 6 * idx, r, mb, false, t, nullptr); }
-                        else { RT_WS(sc, WS_SPHERE); ok = sphere_test<false, FAST>(S.spheres + 2 * idx, r, mb, false, t, nullptr); }
-                        if (ok && (!leaf_rule || t >= 0.0f) && (t < best_t || (has && t == best_t && tested_earlier(sc, slot0 + e, best_slot)))) {
-                            has = true; best_t = t; best_slot = slot0 + e; best.t = t; best.cls = cls; best.idx = idx;
-                            if (ANY || t < stop_below) return true;
-                            prune_t = (stop_below > -INFINITY) ? stop_below : t;       // t >= stop_below here
-                        }
+        const bool last = c >= first_last;                    // the children are runs (or, of a run, primitives)
+        // entry distance (never below 0; NaN counts as 0) and exit distance (capped by what is still worth a visit) per
+        // child; a child is skipped only on a certain miss: any NaN makes the comparison false and the child is visited.
+        // key = entry distance with the child number in the two lowest bits, all ones for a child that is skipped
+        unsigned key[4];
+#define RT_CHILD(k, m) do { \
+            const float tn = max3f(__builtin_fmaf(nx.m, q.rn.x, q.cn.x), __builtin_fmaf(ny.m, q.rn.y, q.cn.y), __builtin_fmaf(nz.m, q.rn.z, q.cn.z)); \
+            const float tf = min3f(__builtin_fmaf(fx.m, q.rf.x, q.cf.x), __builtin_fmaf(fy.m, q.rf.y, q.cf.y), __builtin_fmaf(fz.m, q.rf.z, q.cf.z)); \
+            const float d = fmaxf(tn, 0.0f), t = fminf(tf, prune_t); \
+            const bool go = !(d > t) && !(last && !is_run && pairs && k >= 2); \
+            key[k] = go ? ((__float_as_uint(d) & ~3u) | (unsigned)k) : 0xffffffffu; } while (0)
+        RT_CHILD(0, x); RT_CHILD(1, y); RT_CHILD(2, z); RT_CHILD(3, w);
+#undef RT_CHILD
+        if (is_run) {
+            // the run's primitives whose box is worth a visit, nearest box first (one copy of the primitive tests)
+            RT_WS(sc, WS_RUN);
+            for (;;) {
+                const unsigned m = min(min(key[0], key[1]), min(key[2], key[3]));
+                if (m == 0xffffffffu) break;
+                if (__uint_as_float(m & ~3u) > prune_t) break;                 // a primitive tested meanwhile brought the bound down
+                const unsigned k = m & 3u;
+                key[0] = k == 0u ? 0xffffffffu : key[0]; key[1] = k == 1u ? 0xffffffffu : key[1];
+                key[2] = k == 2u ? 0xffffffffu : key[2]; key[3] = k == 3u ? 0xffffffffu : key[3];
+                const unsigned entry = (unsigned)(k == 0u ? ev.x : k == 1u ? ev.y : k == 2u ? ev.z : ev.w);
+                if (entry == 0xffffffffu) continue;
+                const int cls = (int)(entry >> 30), idx = (int)(entry & 0x3fffffffu);
+                float t; bool ok;
+                if (cls == 0) { RT_WS(sc, WS_PLANE); ok = plane_test<false, FAST>(S.planes + 3 * idx, S.edges, nullptr, r, false, t, nullptr); }
+                else if (cls == 1) { RT_WS(sc, WS_CUBE); ok = cube_test<false, FAST>(S.cubes + 6 * idx, r, mb, false, t, nullptr); }
+                else { RT_WS(sc, WS_SPHERE); ok = sphere_test<false, FAST>(S.spheres + 2 * idx, r, mb, false, t, nullptr); }
+                if (ok && (!leaf_rule || t >= 0.0f) && !(t > best_t)) {
+                    // exact tie between two reported distances: the primitive the reference tests first wins (strict '<'
+                    // in its loops); word 7 of the run's record keeps every primitive's place in that order
+                    unsigned ord = 0;
+                    if (has && t == best_t) {
+                        const int4 ov = *(const int4*)(base + (off + 112u));
+                        ord = (unsigned)(k == 0u ? ov.x : k == 1u ? ov.y : k == 2u ? ov.z : ov.w);
+                        if (!(ord < best_order)) continue;
+                    } else if (!(t < best_t)) continue;                          // NaN
+                    else if (!ANY) {
+                        const int4 ov = *(const int4*)(base + (off + 112u));
+                        ord = (unsigned)(k == 0u ? ov.x : k == 1u ? ov.y : k == 2u ? ov.z : ov.w);
                     }
+                    has = true; best_t = t; best_order = ord; best.t = t; best.cls = cls; best.idx = idx;
+                    if (ANY || t < stop_below) return true;
+                    prune_t = (stop_below > -INFINITY) ? stop_below : t;       // t >= stop_below here
                 }
             }
             if (sp == 0) break;
-            --sp; h = stack[sp * RT_BLOCK];
+            --sp; c = (unsigned)stack[sp * RT_BLOCK];
             continue;
         }
-        // interior children worth a visit, nearest first: sort keys = entry distance (never negative here; NaN counts as
-        // nearest) with the child number in the two lowest bits
-        unsigned key[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float d = (tn4[k] > 0.0f) ? tn4[k] : 0.0f;                      // NaN and negative distances: 0
-            key[k] = go4[k] ? ((__float_as_uint(d) & ~3u) | (unsigned)k) : 0xffffffffu;
-        }
+        // children worth a visit, nearest first
 #define RT_CSWAP(i, j) do { const unsigned lo = min(key[i], key[j]), hi = max(key[i], key[j]); key[i] = lo; key[j] = hi; } while (0)
         RT_CSWAP(0, 1); RT_CSWAP(2, 3); RT_CSWAP(0, 2); RT_CSWAP(1, 3); RT_CSWAP(1, 2);
 #undef RT_CSWAP
+        const unsigned i0 = c - first_last;
+        const unsigned kid0 = last ? n_rec + (pairs ? 2u * i0 : 4u * i0) : 4u * c + 1u;
         if (key[0] != 0xffffffffu) {
-            if (key[3] != 0xffffffffu) { stack[sp * RT_BLOCK] = kid0 + (int)(key[3] & 3u); ++sp; }
-            if (key[2] != 0xffffffffu) { stack[sp * RT_BLOCK] = kid0 + (int)(key[2] & 3u); ++sp; }
-            if (key[1] != 0xffffffffu) { stack[sp * RT_BLOCK] = kid0 + (int)(key[1] & 3u); ++sp; }
-            h = kid0 + (int)(key[0] & 3u);
+            if (key[3] != 0xffffffffu) { stack[sp * RT_BLOCK] = (int)(kid0 + (key[3] & 3u)); ++sp; }
+            if (key[2] != 0xffffffffu) { stack[sp * RT_BLOCK] = (int)(kid0 + (key[2] & 3u)); ++sp; }
+            if (key[1] != 0xffffffffu) { stack[sp * RT_BLOCK] = (int)(kid0 + (key[1] & 3u)); ++sp; }
+            c = kid0 + (key[0] & 3u);
         } else {
             if (sp == 0) break;
-            --sp; h = stack[sp * RT_BLOCK];
+            --sp; c = (unsigned)stack[sp * RT_BLOCK];
         }
     }
     return has;
@@ -614,7 +603,7 @@ DEVI bool trace(const DevScene& sc, const DevFrame& f, const float4* __restrict_
                 int* __restrict__ stack, const Ray& r, bool with_fallback, Best& best, float stop_below = -INFINITY) {
     const bool mb = f.motion_blur != 0;
     RT_WS(sc, WS_TRACE);
-    SubRay q; q.rcp = q.cn = q.cf = mk(0.0f, 0.0f, 0.0f); q.px = q.py = q.pz = true;
+    SubRay q; q.rn = q.rf = q.cn = q.cf = mk(0.0f, 0.0f, 0.0f); q.on_x = q.on_y = q.on_z = q.of_x = q.of_y = q.of_z = 0u;
     if (SUB) q = make_sub_ray(sc, r);
     // the file-order set as its hierarchy reads it (records in hierarchy order): what best.idx of a file-order hit indexes
     const DevPrimSet& FS = SUB ? sc.walkset : sc.fileset;

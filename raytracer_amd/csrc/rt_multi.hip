@@ -33,6 +33,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool load(std::string& err) {
         if (so) return true;
@@ -40,7 +41,7 @@ struct Rccl {
         if (!so) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
 #define RT_SYM(field, sym) do { *(void**)(&field) = dlsym(so, sym); if (!field) { err = std::string("librccl lacks ") + sym; return false; } } while (0)
         RT_SYM(CommInitAll, "ncclCommInitAll"); RT_SYM(CommDestroy, "ncclCommDestroy"); RT_SYM(GroupStart, "ncclGroupStart");
-        RT_SYM(GroupEnd, "ncclGroupEnd"); RT_SYM(Send, "ncclSend"); RT_SYM(Recv, "ncclRecv"); RT_SYM(GetErrorString, "ncclGetErrorString");
+        RT_SYM(GroupEnd, "ncclGroupEnd"); RT_SYM(Send, "ncclSend"); RT_SYM(Recv, "ncclRecv"); RT_SYM(Broadcast, "ncclBroadcast"); RT_SYM(GetErrorString, "ncclGetErrorString");
 #undef RT_SYM
         return true;
     }
@@ -60,6 +61,7 @@ struct rt_multi {
     unsigned char* image = nullptr;          // first device: row-major frame
     size_t block_bytes = 0, image_bytes = 0;
     bool use_rccl = false;
+    bool device_broadcast = true;            // rt_multi_upload: one upload + build, then the device arrays go to the peers (option "device_broadcast")
     Rccl rccl;
     std::vector<ncclComm_t> comms;
     std::vector<hipEvent_t> done;            // per device: block rendered (memcpy transport only)
@@ -130,26 +132,71 @@ int32_t rt_multi_uses_rccl(const rt_multi* m) { return m && m->use_rccl ? 1 : 0;
 rt_ctx* rt_multi_context(rt_multi* m, int32_t rank) { return (m && rank >= 0 && rank < m->n) ? m->ctx[(size_t)rank] : nullptr; }
 
 int rt_multi_set_option(rt_multi* m, const char* name, int64_t value) {
-    if (!m) return RT_ERR_ARG;
+    if (!m || !name) return RT_ERR_ARG;
+    if (std::strcmp(name, "device_broadcast") == 0) { m->device_broadcast = value != 0; return RT_OK; }
     for (int i = 0; i < m->n; ++i)
         if (rt_set_option(m->ctx[(size_t)i], name, value) != RT_OK) return m->fail(RT_ERR_ARG, rt_last_error(m->ctx[(size_t)i]));
     return RT_OK;
 }
 
-// The scene and the host-built BVH go to every device (the "broadcast once per frame set"): each context copies what
-// it needs and builds its second-level hierarchies on its own GPU, one host thread per device.
+// The scene and the BVH reach every device once per frame set.  Default: the first device takes the host arrays, builds
+// its second-level hierarchies and the records the kernels read; the other contexts adopt that layout (they allocate, no
+// host work, no build) and every device array is then broadcast from the first device - one ncclBroadcast per array,
+// grouped over the devices, each on its context's stream (RCCL over xGMI; device copies when the list repeats a device
+// id).  With the option "device_broadcast" off every device uploads and builds for itself, one host thread per device.
+static int multi_broadcast_scene(rt_multi* m) {
+    std::vector<unsigned char> layout((size_t)rt_scene_layout_bytes());
+    if (rt_export_scene_layout(m->ctx[0], layout.data(), layout.size()) != RT_OK) return m->fail(RT_ERR_STATE, rt_last_error(m->ctx[0]));
+    for (int i = 1; i < m->n; ++i)
+        if (rt_adopt_scene_layout(m->ctx[(size_t)i], layout.data(), layout.size()) != RT_OK)
+            return m->fail(RT_ERR_HIP, std::string("device ") + std::to_string(m->devices[(size_t)i]) + ": " + rt_last_error(m->ctx[(size_t)i]));
+    const int n_arrays = rt_scene_array_count(m->ctx[0]);
+    for (int a = 0; a < n_arrays; ++a) {
+        std::vector<void*> ptr((size_t)m->n, nullptr); uint64_t bytes = 0;
+        for (int i = 0; i < m->n; ++i) {
+            uint64_t b = 0;
+            if (rt_scene_array(m->ctx[(size_t)i], a, &ptr[(size_t)i], &b) != RT_OK) return m->fail(RT_ERR_STATE, rt_last_error(m->ctx[(size_t)i]));
+            if (i == 0) bytes = b; else if (b < bytes) return m->fail(RT_ERR_STATE, "adopted scene array smaller than its source");
+        }
+        if (!bytes) continue;
+        if (m->use_rccl) {
+            RTM_TRY(m->nccl(m->rccl.GroupStart(), "ncclGroupStart"));
+            ncclResult_t first_bad = 0;
+            for (int i = 0; i < m->n && first_bad == 0; ++i)
+                first_bad = m->rccl.Broadcast(ptr[(size_t)i], ptr[(size_t)i], (size_t)bytes, kNcclUint8, 0, m->comms[(size_t)i], (hipStream_t)rt_get_stream(m->ctx[(size_t)i]));
+            const ncclResult_t end = m->rccl.GroupEnd();
+            if (first_bad != 0) return m->nccl(first_bad, "ncclBroadcast");
+            RTM_TRY(m->nccl(end, "ncclGroupEnd"));
+        } else {
+            for (int i = 1; i < m->n; ++i) {
+                RTM_TRY(m->hip(hipSetDevice(m->devices[(size_t)i]), "hipSetDevice"));
+                RTM_TRY(m->hip(hipMemcpyAsync(ptr[(size_t)i], ptr[0], (size_t)bytes, hipMemcpyDefault, (hipStream_t)rt_get_stream(m->ctx[(size_t)i])), "hipMemcpyAsync"));
+            }
+        }
+    }
+    for (int i = 0; i < m->n; ++i) if (rt_synchronize(m->ctx[(size_t)i]) != RT_OK) return m->fail(RT_ERR_HIP, rt_last_error(m->ctx[(size_t)i]));
+    return RT_OK;
+}
+
 int rt_multi_upload(rt_multi* m, const rt_scene* scene, const rt_bvh_node* nodes, int32_t n_nodes, const int32_t* prim_ids, int32_t n_prim_ids) {
     if (!m || !scene) return RT_ERR_ARG;
     m->uploaded = false;
     std::vector<int> rc((size_t)m->n, RT_OK);
-    std::vector<std::thread> th;
-    for (int i = 0; i < m->n; ++i)
-        th.emplace_back([&, i]() {
-            int r = rt_upload_scene(m->ctx[(size_t)i], scene);
-            if (r == RT_OK) r = rt_upload_bvh(m->ctx[(size_t)i], nodes, n_nodes, prim_ids, n_prim_ids);
-            rc[(size_t)i] = r;
-        });
-    for (auto& t : th) t.join();
+    if (m->device_broadcast && m->n > 1) {
+        int r = rt_upload_scene(m->ctx[0], scene);
+        if (r == RT_OK) r = rt_upload_bvh(m->ctx[0], nodes, n_nodes, prim_ids, n_prim_ids);
+        if (r != RT_OK) return m->fail(r, std::string("device ") + std::to_string(m->devices[0]) + ": " + rt_last_error(m->ctx[0]));
+        RTM_TRY(multi_broadcast_scene(m));
+    } else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < m->n; ++i)
+            th.emplace_back([&, i]() {
+                int r = rt_upload_scene(m->ctx[(size_t)i], scene);
+                if (r == RT_OK) r = rt_upload_bvh(m->ctx[(size_t)i], nodes, n_nodes, prim_ids, n_prim_ids);
+                rc[(size_t)i] = r;
+            });
+        for (auto& t : th) t.join();
+    }
     for (int i = 0; i < m->n; ++i) if (rc[(size_t)i] != RT_OK) return m->fail(rc[(size_t)i], std::string("device ") + std::to_string(m->devices[(size_t)i]) + ": " + rt_last_error(m->ctx[(size_t)i]));
     m->width = (int)scene->camera.res_x; m->height = (int)scene->camera.res_y;
     const size_t bb = (size_t)rt_max_tiles_per_rank(m->ctx[0]) * RT_TILE_PIX * 3, ib = (size_t)m->width * (size_t)m->height * 3;

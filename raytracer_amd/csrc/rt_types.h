@@ -21,7 +21,7 @@ __host__ __device__ inline size_t rt_sub_motion_offset(int h) {
 #define RT_MAX_LDS_LEAVES  512       // leaf records staged in LDS (32 B each)
 #define RT_SUB_LEAF        4         // second-level hierarchy: primitives per entry run
 #define RT_SUB_MIN_GROUP   8         // groups of at most this many primitives are tested one by one
-#define RT_SUB_STACK       40        // most second-level traversal stack entries per thread (LDS); see rt_sub_stack_entries
+#define RT_SUB_STACK       44        // most second-level traversal stack entries per thread (LDS); see rt_sub_stack_entries
 #define RT_SUB_MAX_DEPTH   24        // deepest second-level hierarchy (16M runs)
 
 // ---- primitives ---------------------------------------------------------------------------------------
@@ -54,11 +54,12 @@ struct DevPrimSet {
 // BVH node : 2 words (min.xyz, bits skip) (max.xyz, bits leaf | -1), laid out in the order a traversal that
 //            visits the right child first meets them; skip = index of the next node once this subtree is done.
 // leaf     : 2 words of ints (plane_first, plane_count, cube_first, cube_count)
-//            (sphere_first, sphere_count, second-level root | -1, depth of that hierarchy)
-// second-level node : 4 words, heap order per group, see sub_trace in rt_kernels.hip; entries: four slots per run,
-//            class << 30 | index in the primitive set, or -1.  The groups' records are stored in hierarchy order (a run's
-//            primitives are neighbours in their class arrays); sub_order keeps, per slot, class << 30 | the index the
-//            primitive had in the reference's testing order, which decides exact ties
+//            (sphere_first, sphere_count, first record of the leaf's second-level hierarchy | -1, depth of that hierarchy)
+// second-level record : 8 words (16 in scenes with moving primitives), see sub_trace in rt_kernels.hip: the boxes of
+//            four children plane by plane; a run's record also holds its (up to four) entries, class << 30 | index in the
+//            primitive set or -1, and per entry class << 30 | the index the primitive had in the reference's testing
+//            order, which decides exact ties.  The groups' primitive records are stored in hierarchy order (a run's
+//            primitives are neighbours in their class arrays)
 struct DevScene {
     const float4* nodes;  int n_nodes;
     const int4* leaves;   int n_leaves;
@@ -71,10 +72,10 @@ struct DevScene {
     const int4* tex_desc;
     const float4* texels;
     const float4* lights; int n_lights;
-    const float4* sub_nodes;       // second-level hierarchies of all groups (NULL when no group has one)
-    const int* sub_entries;
-    const int* sub_order;          // per entry slot: the primitive's place in the reference's testing order (NULL: the entry itself is that)
-    int file_sub_root;             // second-level root over the whole file-order set, or -1
+    const float4* sub_nodes;       // records of the second-level hierarchies of all groups (NULL when no group has one)
+    const int* sub_entries;        // build products (entry slots, and per slot the primitive's place in the reference's testing
+    const int* sub_order;          //   order, NULL: the entry itself is that); the kernels read the copies inside the run records
+    int file_sub_root;             // first record of the hierarchy over the whole file-order set, or -1
     int file_sub_depth;            // depth of that hierarchy
     int sub_stride;                // words per second-level node: 4 (boxes over the whole motion) or 8 (boxes per time, see rt_sub_motion_offset)
     int sub_stack_entries;         // traversal stack entries per thread, see rt_sub_stack_entries: any hierarchy of the scene
@@ -182,9 +183,10 @@ static inline int rt_lds_prim_words(const DevScene& sc) {
            2 * (sc.fileset.n_spheres + sc.leafset.n_spheres) + 3 * (sc.fileset.n_planes + sc.fileset.n_cubes + sc.fileset.n_spheres);
 }
 
-// Stack entries a walk of a hierarchy of `depth` levels needs: a step that skips a level pushes up to three siblings,
-// and there are ceil(depth / 2) such steps on a root-to-run path.
-static inline int rt_sub_stack_entries(int depth) { return 3 * ((depth + 1) / 2) + 2; }
+// Stack entries a walk of a hierarchy of `depth` levels needs: a step (two binary levels, or the step from the last
+// level to the runs) pushes up to three siblings, and there are ceil(depth / 2) + 1 steps on a path from the root to a
+// primitive.
+static inline int rt_sub_stack_entries(int depth) { return 3 * ((depth + 1) / 2 + 1) + 2; }
 
 // kernel launchers (rt_kernels.hip)
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);

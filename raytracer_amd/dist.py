@@ -94,6 +94,32 @@ def broadcast_scene(loaded, with_bvh: bool, src: int = 0, device: torch.device |
     return loaded if dist.get_rank() == src else api.PackedScene(blob)
 
 
+class _DeviceBytes:
+    """A (device pointer, bytes) pair as something torch.as_tensor can wrap without copying."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def broadcast_device_scene(renderer, src: int = 0, device: torch.device | None = None):
+    """The scene broadcast of the multi-GPU design, device to device: rank `src` has uploaded the scene and the tree into
+    `renderer` (parse, host BVH build, upload and on-GPU construction happen there once); every other rank's `renderer`
+    adopts the layout - it allocates, nothing else - and receives every device array straight into place with one
+    torch.distributed.broadcast each (RCCL over xGMI with the nccl backend).  No rank but `src` touches host scene data."""
+    import numpy as np
+    if not dist.is_initialized():
+        return
+    rank = dist.get_rank()
+    layout = broadcast_bytes(renderer.export_layout() if rank == src else None, src, device)
+    if rank != src:
+        renderer.adopt_layout(layout)
+    for ptr, nbytes in renderer.scene_arrays():
+        if nbytes:
+            t = torch.as_tensor(_DeviceBytes(ptr, nbytes), device=device)
+            dist.broadcast(t, src)
+    torch.cuda.synchronize(device)
+
+
 class FramePipeline:
     """Frames of a multi-rank run, pipelined: frame k is rendered on `render_stream` into one of two blocks; its gather
     runs beside the kernels of frame k + 1 (on the communicator's stream) and rank 0 re-orders it into the row-major

@@ -67,6 +67,67 @@ def test_frames_enqueued_back_to_back_do_not_overwrite_blocks_still_being_gather
     m.close(); ls.close()
 
 
+@pytest.mark.parametrize("n,flags", [(0, ["-t", "-rd", "2", "-ss", "-sss", "4"]), (30000, ["-r", "-rd", "2", "-grs", "1"]), (30000, ["-u"])])
+def test_adopted_device_scene_renders_the_source_frames(n, flags, textures_dir):
+    """The scene broadcast of the multi-GPU path, as far as one GPU goes: a second context adopts the layout of an
+    uploaded scene, the device arrays are copied into it, and it renders the source's frames bit for bit - sharded too -
+    without any host scene data.  Small scene (no second-level hierarchies) and 30 000 primitives (hierarchies of the
+    leaves and of the file-order set, records in hierarchy order)."""
+    from raytracer_amd import dist as rdist, scenegen as sg
+    cfg, _ = api.parse_args(flags); cfg.seed = 5
+    ls = api.ArrayScene(sg.random_prims(n, 3, transparent_frac=0.1), (640, 360)) if n else api.LoadedScene(cases.SCENES["glass_tex"](), cfg, textures_dir)
+    src = api.Renderer(0); src.upload(ls, with_bvh=bool(cfg.bvh))
+    want, st = src.render(cfg)
+    assert want.max() > 0
+    # (1) the library's own device copies
+    a = api.Renderer(0); a.adopt_from(src)
+    got, st_a = a.render(cfg)
+    assert np.array_equal(got, want) and st_a.total_rays() == st.total_rays()
+    # (2) layout blob + every array moved by the caller, here with torch copies between the two contexts' arrays
+    b = api.Renderer(0)
+    layout = src.export_layout()
+    b.adopt_layout(layout)
+    assert (b.width, b.height) == (src.width, src.height)
+    pairs = list(zip(src.scene_arrays(), b.scene_arrays()))
+    assert len(pairs) >= 5
+    for (sp, sn), (dp, dn) in pairs:
+        assert dn >= sn and sp and dp
+        torch.as_tensor(rdist._DeviceBytes(dp, sn), device="cuda").copy_(torch.as_tensor(rdist._DeviceBytes(sp, sn), device="cuda"))
+    torch.cuda.synchronize()
+    got_b, _ = b.render(cfg)
+    assert np.array_equal(got_b, want)
+    # sharded frames of the adopted scene assemble to the same image
+    blocks = []
+    for rank in range(3):
+        b.set_shard(rank, 3)
+        blk, _ = b.render(cfg); blocks.append(blk.copy())
+    assert np.array_equal(api.assemble_tiles_numpy(blocks, src.width, src.height), want)
+    # a tree cannot be uploaded into an adopted scene; a fresh upload replaces it
+    with pytest.raises(api.RtError) as e:
+        hb = ls.bvh()
+        a._check(api.lib().rt_upload_bvh(a._ctx, hb.nodes, hb.n_nodes, hb.prim_ids, hb.n_prim_ids))
+    assert e.value.code == -3
+    a.upload(ls, with_bvh=bool(cfg.bvh))
+    assert np.array_equal(a.render(cfg)[0], want)
+    with pytest.raises(api.RtError):
+        b.adopt_layout(layout[:100])
+    src.close(); a.close(); b.close(); ls.close()
+
+
+def test_device_broadcast_and_per_device_uploads_give_the_same_frames(textures_dir):
+    """rt_multi_upload: one upload + build and a broadcast of the device arrays (default) against every device uploading
+    and building for itself (option device_broadcast = 0)."""
+    from raytracer_amd import scenegen as sg
+    cfg, _ = api.parse_args(["-r", "-rd", "2", "-grs", "1"])
+    ls = api.ArrayScene(sg.random_prims(20000, 8, transparent_frac=0.1), (480, 270))
+    want = single(ls, cfg)
+    for bc in (1, 0):
+        m = api.MultiRenderer([0, 0, 0]); m.set_option("device_broadcast", bc); m.upload(ls)
+        assert np.array_equal(m.render(cfg), want), f"device_broadcast {bc}"
+        m.close()
+    ls.close()
+
+
 def test_multi_errors_and_no_bvh():
     with pytest.raises(api.RtError):
         api.MultiRenderer([0, 99])                      # no such device

@@ -1,0 +1,13 @@
+#!/bin/bash
+set -u
+cd "$(dirname "$0")/../.." || exit 1
+O=gpurun_out/run4; mkdir -p $O; rm -f $O/ab.log
+for v in "" _w3 _w5 _w6; do
+  export RT_AMD_LIB=$PWD/raytracer_amd/librt_amd$v.so
+  echo "== lib$v" >> $O/ab.log
+  timeout -k 10 200 python -u tools/ab_option.py --workload config3 --set "" >> $O/ab.log 2>&1 || { echo ab3 failed; tail -5 $O/ab.log; exit 1; }
+  timeout -k 10 200 python -u tools/ab_option.py --workload config3u --set "" >> $O/ab.log 2>&1 || { echo ab3u failed; exit 1; }
+  timeout -k 10 200 python -u tools/ab_option.py --workload config3 --flags="-r -rd 4" --set "" >> $O/ab.log 2>&1 || { echo ab3r failed; exit 1; }
+  timeout -k 10 300 python -u tools/ab_option.py --workload config5s --reps 2 --set "" >> $O/ab.log 2>&1 || { echo ab5 failed; tail -5 $O/ab.log; exit 1; }
+done
+grep -v "amdgpu.ids" $O/ab.log
