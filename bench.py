@@ -174,13 +174,32 @@ def self_launch(args) -> int:
     return child.wait()
 
 
-def load_counters(workload: str) -> dict:
+KERNEL_SOURCES = ["rt_kernels.hip", "rt_context.hip", "rt_build.hip", "rt_types.h", "rt_build.h", "ref_libm.h", "Makefile"]
+
+
+def kernel_sources_sha() -> str:
+    """Identifies the kernel build a set of hardware counters belongs to: SHA-256 over the device sources and the build
+    flags (tools/profile.sh stamps it into the counters it collects; the bench line compares it with the tree it runs from)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update(name.encode()); h.update((ROOT / "raytracer_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def load_counters(workload: str) -> tuple[dict, dict]:
     """Per-kernel, per-launch hardware counters of this workload collected by tools/profile.sh (rocprofv3 --pmc passes),
-    committed as profiles/counters_latest.json."""
+    committed as profiles/counters_latest.json, and where they come from: the stamp of the kernel sources they were
+    collected on, and whether that is the tree this process runs from."""
     f = ROOT / "profiles" / "counters_latest.json"
     if not f.exists():
-        return {}
-    return json.loads(f.read_text()).get(workload, {}).get("kernels", {})
+        return {}, {"file": None}
+    rec = json.loads(f.read_text()).get(workload, {})
+    stamp = rec.get("kernel_sources_sha")
+    here = kernel_sources_sha()
+    origin = {"file": "profiles/counters_latest.json", "kernel_sources_sha": stamp, "this_tree": here, "collected": rec.get("collected"),
+              "stale": bool(rec) and stamp != here}
+    return rec.get("kernels", {}), origin
 
 
 def roofline(st, workload: str, small_scene: bool) -> dict:
@@ -199,7 +218,9 @@ def roofline(st, workload: str, small_scene: bool) -> dict:
         units = st.primary_rays + st.shadow_rays
         total = st.primary_rays * BYTES_PER_EXTEND_RAY + st.shadow_rays * BYTES_PER_SHADOW_RAY + st.nodes_shaded * BYTES_PER_SHADED_HIT
         kernels = {"k_primary_shaded": dict(units=units, bytes_per_unit=total / max(1, units), ms=st.ms_extend_primary, launches=st.launches_extend_primary)}
-    ctr = load_counters(workload)
+    ctr, ctr_origin = load_counters(workload)
+    if ctr_origin.get("stale"):
+        ctr = {}                 # counters of another kernel build say nothing about this one: only live timings are reported
     for name, k in kernels.items():
         n = max(1, k["launches"])
         k["avg_launch_ms"] = k["ms"] / n
@@ -236,7 +257,7 @@ def roofline(st, workload: str, small_scene: bool) -> dict:
            "note": "prescribed per-ray record bytes x rays of the launch / launch duration; this implementation moves fewer bytes "
                    "(primary rays are generated in registers, shadow rays are never stored)"}
     traffic = d.get("hbm_bytes_per_launch")
-    out = {"kernel": dom, "avg_launch_ms": d["avg_launch_ms"], "traffic": traffic, "frame_valu_busy_ms": frame_busy_s * 1e3 if frame_busy_s else None,
+    out = {"kernel": dom, "avg_launch_ms": d["avg_launch_ms"], "traffic": traffic, "counters_from": ctr_origin, "stale": bool(ctr_origin.get("stale")), "frame_valu_busy_ms": frame_busy_s * 1e3 if frame_busy_s else None,
            "traffic_ratio": (traffic / d["bytes_per_launch"]) if (traffic and d["bytes_per_launch"]) else None,
            "hbm_algorithmic": alg, "l2_hit_rate": d.get("l2_hit_rate"), "by_kernel": kernels}
     if small_scene and "valu_issue_frac" in d:
@@ -254,6 +275,11 @@ def roofline(st, workload: str, small_scene: bool) -> dict:
                    note="achieved = HBM bytes of the launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, committed counter pass) / launch duration "
                         "measured live.  The walk of the second-level hierarchies is bound by the latency of dependent node and "
                         "primitive fetches (L2 / Infinity Cache), not by streaming bandwidth; l2_hit_rate is from the same passes")
+    elif ctr_origin.get("stale"):
+        out.update(bound="valu" if small_scene else "hbm", achieved=None, peak=VALU_PEAK_TFLOPS if small_scene else HBM_PEAK_GBS,
+                   unit="TFLOP/s" if small_scene else "GB/s", frac=None,
+                   note="the committed counter pass was collected on other kernel sources (counters_from): no counter-based fraction; "
+                        "hbm_algorithmic is the prescribed record bytes / launch duration measured live")
     else:
         out.update(bound="hbm", achieved=d["GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=d["GBps"] / HBM_PEAK_GBS,
                    note="no committed counter pass for this workload: algorithmic record bytes / launch duration")
@@ -512,7 +538,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
         lit = float((final.reshape(-1, 3).sum(axis=1) > 0).mean())
         import zlib
         crc = zlib.crc32(final.tobytes())                # of the row-major RGB bytes of the last timed frame
-        res = {"workload": describe(name), "value": rays_total / (elapsed / steps), "ms_per_step": 1000.0 * elapsed / steps,
+        res = {"workload": describe(name), "rays_total": rays_total, "value": rays_total / (elapsed / steps), "ms_per_step": 1000.0 * elapsed / steps,
                "steps": steps, "warmup": warmup, "graph_recording_frames": prime_steps, "spp": spp, "frames_in_flight": P, "frame_ms_alone": frame_latency_ms,
                "frame_ms_to_host": to_host, "host_enqueue_ms_per_step": 1000.0 * t_enq / steps, "upload_seconds": upload_s,
                "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3],
@@ -611,6 +637,7 @@ def main():
             "metric": "rays/sec (all ray types), 1080p scene.json" if args.workload == "config2" else f"rays/sec (all ray types), {args.workload}",
             "value": head["value"], "unit": "rays/s", "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"],
             "ms_per_step": head["ms_per_step"], "frame_ms_alone": head["frame_ms_alone"],
+            "value_one_frame_at_a_time": head["rays_total"] / (head["frame_ms_alone"] / 1e3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic: the reference's own ASCII/scene.json (committed as a fixture), no dataset" if wl["scene"] == "ref"
                     else f"the reference's Blend/{wl['scene'][6:]}.blend exported to scene.json text (committed as a fixture)" if wl["scene"].startswith("blend:")

@@ -51,6 +51,13 @@ enum { WS_BOX = 0, WS_GROUP = 1, WS_STEP = 2, WS_PLANE = 3, WS_CUBE = 4, WS_CUBE
 #define RT_SHADOW_WAVES_SUB 3       // no spills at 132-144 registers
 #endif
 
+#ifndef RT_REFILL_LANES
+#define RT_REFILL_LANES 16          // k_shadow's drain: lanes that must be waiting before a wavefront refills / walks the first level
+#endif
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 3            // 152 registers as the compiler allots them
+#endif
+
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
@@ -472,111 +479,152 @@ DEVI float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 // n_rec: run r at n_rec + r, holding the boxes of its own (up to four) primitives, their entries (word 6) and their
 // places in the reference's testing order (word 7).  So a run is searched like any other node - one load round, four
 // box tests - and only the primitives whose box the ray enters before the best hit so far are tested, nearest box first.
-template <bool ANY, bool FAST, bool MOTION>
-DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth, const Ray& r, const SubRay& q, bool mb, bool leaf_rule,
-                    float stop_below, int* __restrict__ stack, Best& best) {
-    float best_t = leaf_rule ? INFINITY : FLT_MAX;
-    // what a subtree must be entered below to be worth a visit: the best distance so far - or, once a caller who only
-    // asks "is the closest distance below stop_below" has a hit at or beyond that value, stop_below itself (nothing
-    // entered later than that can change the answer; which primitive is reported is then not the caller's concern)
-    float prune_t = best_t;
-    unsigned best_order = 0; bool has = false;
-    int sp = 0;
-    unsigned c = 0;                                           // record inside the group
+// State of one ray's walk through one group's records, kept by the caller between steps.
+struct SubWalk {
+    unsigned c;                     // record inside the group that the next step reads
+    int sp;                         // entries on this thread's stack
+    int root;                       // the group's first record
+    unsigned n_rec, first_last;     // first run record; first record of the last level above the runs
+    bool pairs;                     // odd depth: a record of that level has two runs below it, not four
+    float best_t, prune_t;          // closest reported distance so far; what a subtree must be entered below to be worth a visit
+    unsigned best_order; bool has;  // the best hit's place in the reference's testing order; whether there is a hit at all
+};
+
+DEVI void sub_begin(SubWalk& s, int root, int depth, bool leaf_rule) {
     const int levels = (depth + 1) >> 1;                      // record levels above the runs: a step moves two binary levels down
-    const unsigned n_rec = ((1u << (2 * levels)) - 1u) / 3u;  // first run record
-    const unsigned first_last = ((1u << (2 * (levels - 1))) - 1u) / 3u;     // first record of the last level above the runs
-    const bool pairs = (depth & 1) != 0;                      // odd depth: a record of that level has two runs below it, not four
+    s.c = 0; s.sp = 0; s.root = root;
+    s.n_rec = ((1u << (2 * levels)) - 1u) / 3u;
+    s.first_last = ((1u << (2 * (levels - 1))) - 1u) / 3u;
+    s.pairs = (depth & 1) != 0;
+    s.best_t = leaf_rule ? INFINITY : FLT_MAX;
+    // prune_t: the best distance so far - or, once a caller who only asks "is the closest distance below stop_below" has a
+    // hit at or beyond that value, stop_below itself (nothing entered later than that can change the answer; which
+    // primitive is reported is then not the caller's concern)
+    s.prune_t = s.best_t;
+    s.best_order = 0; s.has = false;
+}
+
+enum { SUB_CONTINUE = 0, SUB_EXHAUSTED = 1, SUB_STOPPED = 2 };   // SUB_STOPPED: a hit that ends the search (ANY, or below stop_below)
+
+// First half of a step: the record the walk stands on - four boxes - against the ray.  key[k] = entry distance of child
+// k (never below 0; NaN counts as 0) with the child number in the two lowest bits, or all ones for a child that is
+// skipped; a child is skipped only on a certain miss (any NaN makes the comparison false and the child is visited) or
+// when it is entered beyond what is still worth a visit.  Returns whether the record is a run's (its children are
+// primitives: `ev` = their entries, `off` = the record's byte offset).
+template <bool MOTION>
+DEVI bool sub_boxes(const DevScene& sc, const SubWalk& s, const Ray& r, const SubRay& q, bool mb, unsigned key[4], int4& ev, unsigned& off) {
     // Scenes with moving primitives keep boxes per time; rays at time 0 - every secondary ray, and every ray of a frame
     // without motion blur, where primitives stay at their first location - read the first half of a record only.
     const float tm = (MOTION && mb) ? r.time : 0.0f;
     constexpr unsigned REC = MOTION ? 256u : 128u;
     const char* __restrict__ base = (const char*)sc.sub_nodes;
-    for (;;) {
-        RT_WS(sc, WS_STEP);
-        const unsigned off = ((unsigned)root + c) * REC;      // (the upload keeps every record below 4 GiB)
-        const bool is_run = c >= n_rec;
-        float4 nx = *(const float4*)(base + (off + q.on_x)), ny = *(const float4*)(base + (off + q.on_y)), nz = *(const float4*)(base + (off + q.on_z));
-        float4 fx = *(const float4*)(base + (off + q.of_x)), fy = *(const float4*)(base + (off + q.of_y)), fz = *(const float4*)(base + (off + q.of_z));
-        int4 ev = make_int4(-1, -1, -1, -1);
-        if (is_run) ev = *(const int4*)(base + (off + 96u));
-        if (MOTION && tm != 0.0f) {
-            // boxes per time: planes at time 0 plus time x (their change until time 1)
-            const float4 dnx = *(const float4*)(base + (off + 128u + q.on_x)), dny = *(const float4*)(base + (off + 128u + q.on_y)), dnz = *(const float4*)(base + (off + 128u + q.on_z));
-            const float4 dfx = *(const float4*)(base + (off + 128u + q.of_x)), dfy = *(const float4*)(base + (off + 128u + q.of_y)), dfz = *(const float4*)(base + (off + 128u + q.of_z));
+    RT_WS(sc, WS_STEP);
+    const unsigned c = s.c;
+    off = ((unsigned)s.root + c) * REC;                       // (the upload keeps every record below 4 GiB)
+    const bool is_run = c >= s.n_rec;
+    float4 nx = *(const float4*)(base + (off + q.on_x)), ny = *(const float4*)(base + (off + q.on_y)), nz = *(const float4*)(base + (off + q.on_z));
+    float4 fx = *(const float4*)(base + (off + q.of_x)), fy = *(const float4*)(base + (off + q.of_y)), fz = *(const float4*)(base + (off + q.of_z));
+    ev = make_int4(-1, -1, -1, -1);
+    if (is_run) ev = *(const int4*)(base + (off + 96u));
+    if (MOTION && tm != 0.0f) {
+        // boxes per time: planes at time 0 plus time x (their change until time 1)
+        const float4 dnx = *(const float4*)(base + (off + 128u + q.on_x)), dny = *(const float4*)(base + (off + 128u + q.on_y)), dnz = *(const float4*)(base + (off + 128u + q.on_z));
+        const float4 dfx = *(const float4*)(base + (off + 128u + q.of_x)), dfy = *(const float4*)(base + (off + 128u + q.of_y)), dfz = *(const float4*)(base + (off + 128u + q.of_z));
 #define RT_MOVE(p, dp) p.x = __builtin_fmaf(dp.x, tm, p.x); p.y = __builtin_fmaf(dp.y, tm, p.y); p.z = __builtin_fmaf(dp.z, tm, p.z); p.w = __builtin_fmaf(dp.w, tm, p.w)
-            RT_MOVE(nx, dnx); RT_MOVE(ny, dny); RT_MOVE(nz, dnz); RT_MOVE(fx, dfx); RT_MOVE(fy, dfy); RT_MOVE(fz, dfz);
+        RT_MOVE(nx, dnx); RT_MOVE(ny, dny); RT_MOVE(nz, dnz); RT_MOVE(fx, dfx); RT_MOVE(fy, dfy); RT_MOVE(fz, dfz);
 #undef RT_MOVE
-        }
-        const bool last = c >= first_last;                    // the children are runs (or, of a run, primitives)
-        // entry distance (never below 0; NaN counts as 0) and exit distance (capped by what is still worth a visit) per
-        // child; a child is skipped only on a certain miss: any NaN makes the comparison false and the child is visited.
-        // key = entry distance with the child number in the two lowest bits, all ones for a child that is skipped
-        unsigned key[4];
+    }
+    const bool last = c >= s.first_last;                      // the children are runs (or, of a run, primitives)
 #define RT_CHILD(k, m) do { \
-            const float tn = max3f(__builtin_fmaf(nx.m, q.rn.x, q.cn.x), __builtin_fmaf(ny.m, q.rn.y, q.cn.y), __builtin_fmaf(nz.m, q.rn.z, q.cn.z)); \
-            const float tf = min3f(__builtin_fmaf(fx.m, q.rf.x, q.cf.x), __builtin_fmaf(fy.m, q.rf.y, q.cf.y), __builtin_fmaf(fz.m, q.rf.z, q.cf.z)); \
-            const float d = fmaxf(tn, 0.0f), t = fminf(tf, prune_t); \
-            const bool go = !(d > t) && !(last && !is_run && pairs && k >= 2); \
-            key[k] = go ? ((__float_as_uint(d) & ~3u) | (unsigned)k) : 0xffffffffu; } while (0)
-        RT_CHILD(0, x); RT_CHILD(1, y); RT_CHILD(2, z); RT_CHILD(3, w);
+        const float tn = max3f(__builtin_fmaf(nx.m, q.rn.x, q.cn.x), __builtin_fmaf(ny.m, q.rn.y, q.cn.y), __builtin_fmaf(nz.m, q.rn.z, q.cn.z)); \
+        const float tf = min3f(__builtin_fmaf(fx.m, q.rf.x, q.cf.x), __builtin_fmaf(fy.m, q.rf.y, q.cf.y), __builtin_fmaf(fz.m, q.rf.z, q.cf.z)); \
+        const float d = fmaxf(tn, 0.0f), t = fminf(tf, s.prune_t); \
+        const bool go = !(d > t) && !(last && !is_run && s.pairs && k >= 2); \
+        key[k] = go ? ((__float_as_uint(d) & ~3u) | (unsigned)k) : 0xffffffffu; } while (0)
+    RT_CHILD(0, x); RT_CHILD(1, y); RT_CHILD(2, z); RT_CHILD(3, w);
 #undef RT_CHILD
-        if (is_run) {
-            // the run's primitives whose box is worth a visit, nearest box first (one copy of the primitive tests)
-            RT_WS(sc, WS_RUN);
-            for (;;) {
-                const unsigned m = min(min(key[0], key[1]), min(key[2], key[3]));
-                if (m == 0xffffffffu) break;
-                if (__uint_as_float(m & ~3u) > prune_t) break;                 // a primitive tested meanwhile brought the bound down
-                const unsigned k = m & 3u;
-                key[0] = k == 0u ? 0xffffffffu : key[0]; key[1] = k == 1u ? 0xffffffffu : key[1];
-                key[2] = k == 2u ? 0xffffffffu : key[2]; key[3] = k == 3u ? 0xffffffffu : key[3];
-                const unsigned entry = (unsigned)(k == 0u ? ev.x : k == 1u ? ev.y : k == 2u ? ev.z : ev.w);
-                if (entry == 0xffffffffu) continue;
-                const int cls = (int)(entry >> 30), idx = (int)(entry & 0x3fffffffu);
-                float t; bool ok;
-                if (cls == 0) { RT_WS(sc, WS_PLANE); ok = plane_test<false, FAST>(S.planes + 3 * idx, S.edges, nullptr, r, false, t, nullptr); }
-                else if (cls == 1) { RT_WS(sc, WS_CUBE); ok = cube_test<false, FAST>(S.cubes + 6 * idx, r, mb, false, t, nullptr); }
-                else { RT_WS(sc, WS_SPHERE); ok = sphere_test<false, FAST>(S.spheres + 2 * idx, r, mb, false, t, nullptr); }
-                if (ok && (!leaf_rule || t >= 0.0f) && !(t > best_t)) {
-                    // exact tie between two reported distances: the primitive the reference tests first wins (strict '<'
-                    // in its loops); word 7 of the run's record keeps every primitive's place in that order
-                    unsigned ord = 0;
-                    if (has && t == best_t) {
-                        const int4 ov = *(const int4*)(base + (off + 112u));
-                        ord = (unsigned)(k == 0u ? ov.x : k == 1u ? ov.y : k == 2u ? ov.z : ov.w);
-                        if (!(ord < best_order)) continue;
-                    } else if (!(t < best_t)) continue;                          // NaN
-                    else if (!ANY) {
-                        const int4 ov = *(const int4*)(base + (off + 112u));
-                        ord = (unsigned)(k == 0u ? ov.x : k == 1u ? ov.y : k == 2u ? ov.z : ov.w);
-                    }
-                    has = true; best_t = t; best_order = ord; best.t = t; best.cls = cls; best.idx = idx;
-                    if (ANY || t < stop_below) return true;
-                    prune_t = (stop_below > -INFINITY) ? stop_below : t;       // t >= stop_below here
-                }
-            }
-            if (sp == 0) break;
-            --sp; c = (unsigned)stack[sp * RT_BLOCK];
-            continue;
-        }
-        // children worth a visit, nearest first
+    return is_run;
+}
+
+// Next record of the walk: the stack's top, or none.
+DEVI int sub_pop(SubWalk& s, const int* __restrict__ stack) {
+    if (s.sp == 0) return SUB_EXHAUSTED;
+    --s.sp; s.c = (unsigned)stack[s.sp * RT_BLOCK];
+    return SUB_CONTINUE;
+}
+
+// Second half of a step on a record above the runs: the children worth a visit, nearest first.
+DEVI int sub_descend(SubWalk& s, unsigned key[4], int* __restrict__ stack) {
 #define RT_CSWAP(i, j) do { const unsigned lo = min(key[i], key[j]), hi = max(key[i], key[j]); key[i] = lo; key[j] = hi; } while (0)
-        RT_CSWAP(0, 1); RT_CSWAP(2, 3); RT_CSWAP(0, 2); RT_CSWAP(1, 3); RT_CSWAP(1, 2);
+    RT_CSWAP(0, 1); RT_CSWAP(2, 3); RT_CSWAP(0, 2); RT_CSWAP(1, 3); RT_CSWAP(1, 2);
 #undef RT_CSWAP
-        const unsigned i0 = c - first_last;
-        const unsigned kid0 = last ? n_rec + (pairs ? 2u * i0 : 4u * i0) : 4u * c + 1u;
-        if (key[0] != 0xffffffffu) {
-            if (key[3] != 0xffffffffu) { stack[sp * RT_BLOCK] = (int)(kid0 + (key[3] & 3u)); ++sp; }
-            if (key[2] != 0xffffffffu) { stack[sp * RT_BLOCK] = (int)(kid0 + (key[2] & 3u)); ++sp; }
-            if (key[1] != 0xffffffffu) { stack[sp * RT_BLOCK] = (int)(kid0 + (key[1] & 3u)); ++sp; }
-            c = kid0 + (key[0] & 3u);
-        } else {
-            if (sp == 0) break;
-            --sp; c = (unsigned)stack[sp * RT_BLOCK];
+    const unsigned c = s.c;
+    const bool last = c >= s.first_last;
+    const unsigned i0 = c - s.first_last;
+    const unsigned kid0 = last ? s.n_rec + (s.pairs ? 2u * i0 : 4u * i0) : 4u * c + 1u;
+    if (key[0] != 0xffffffffu) {
+        if (key[3] != 0xffffffffu) { stack[s.sp * RT_BLOCK] = (int)(kid0 + (key[3] & 3u)); ++s.sp; }
+        if (key[2] != 0xffffffffu) { stack[s.sp * RT_BLOCK] = (int)(kid0 + (key[2] & 3u)); ++s.sp; }
+        if (key[1] != 0xffffffffu) { stack[s.sp * RT_BLOCK] = (int)(kid0 + (key[1] & 3u)); ++s.sp; }
+        s.c = kid0 + (key[0] & 3u);
+        return SUB_CONTINUE;
+    }
+    return sub_pop(s, stack);
+}
+
+// One step of the walk: one record - four boxes - and, for a run's record, the tests of its primitives.
+template <bool ANY, bool FAST, bool MOTION>
+DEVI int sub_step(const DevScene& sc, const DevPrimSet& S, SubWalk& s, const Ray& r, const SubRay& q, bool mb, bool leaf_rule,
+                  float stop_below, int* __restrict__ stack, Best& best) {
+    unsigned key[4]; int4 ev; unsigned off;
+    const char* __restrict__ base = (const char*)sc.sub_nodes;
+    if (!sub_boxes<MOTION>(sc, s, r, q, mb, key, ev, off)) return sub_descend(s, key, stack);
+    // the run's primitives whose box is worth a visit, nearest box first (one copy of the primitive tests)
+    RT_WS(sc, WS_RUN);
+    for (;;) {
+        const unsigned m = min(min(key[0], key[1]), min(key[2], key[3]));
+        if (m == 0xffffffffu) break;
+        if (__uint_as_float(m & ~3u) > s.prune_t) break;                       // a primitive tested meanwhile brought the bound down
+        const unsigned k = m & 3u;
+        key[0] = k == 0u ? 0xffffffffu : key[0]; key[1] = k == 1u ? 0xffffffffu : key[1];
+        key[2] = k == 2u ? 0xffffffffu : key[2]; key[3] = k == 3u ? 0xffffffffu : key[3];
+        const unsigned entry = (unsigned)(k == 0u ? ev.x : k == 1u ? ev.y : k == 2u ? ev.z : ev.w);
+        if (entry == 0xffffffffu) continue;
+        const int cls = (int)(entry >> 30), idx = (int)(entry & 0x3fffffffu);
+        float t; bool ok;
+        if (cls == 0) { RT_WS(sc, WS_PLANE); ok = plane_test<false, FAST>(S.planes + 3 * idx, S.edges, nullptr, r, false, t, nullptr); }
+        else if (cls == 1) { RT_WS(sc, WS_CUBE); ok = cube_test<false, FAST>(S.cubes + 6 * idx, r, mb, false, t, nullptr); }
+        else { RT_WS(sc, WS_SPHERE); ok = sphere_test<false, FAST>(S.spheres + 2 * idx, r, mb, false, t, nullptr); }
+        if (ok && (!leaf_rule || t >= 0.0f) && !(t > s.best_t)) {
+            // exact tie between two reported distances: the primitive the reference tests first wins (strict '<'
+            // in its loops); word 7 of the run's record keeps every primitive's place in that order
+            unsigned ord = 0;
+            if (s.has && t == s.best_t) {
+                const int4 ov = *(const int4*)(base + (off + 112u));
+                ord = (unsigned)(k == 0u ? ov.x : k == 1u ? ov.y : k == 2u ? ov.z : ov.w);
+                if (!(ord < s.best_order)) continue;
+            } else if (!(t < s.best_t)) continue;                                // NaN
+            else if (!ANY) {
+                const int4 ov = *(const int4*)(base + (off + 112u));
+                ord = (unsigned)(k == 0u ? ov.x : k == 1u ? ov.y : k == 2u ? ov.z : ov.w);
+            }
+            s.has = true; s.best_t = t; s.best_order = ord; best.t = t; best.cls = cls; best.idx = idx;
+            if (ANY || t < stop_below) return SUB_STOPPED;
+            s.prune_t = (stop_below > -INFINITY) ? stop_below : t;             // t >= stop_below here
         }
     }
-    return has;
+    return sub_pop(s, stack);
+}
+
+template <bool ANY, bool FAST, bool MOTION>
+DEVI bool sub_trace(const DevScene& sc, const DevPrimSet& S, int root, int depth, const Ray& r, const SubRay& q, bool mb, bool leaf_rule,
+                    float stop_below, int* __restrict__ stack, Best& best) {
+    SubWalk s;
+    sub_begin(s, root, depth, leaf_rule);
+    for (;;) {
+        const int st = sub_step<ANY, FAST, MOTION>(sc, S, s, r, q, mb, leaf_rule, stop_below, stack, best);
+        if (st != SUB_CONTINUE) return st == SUB_STOPPED || s.has;
+    }
 }
 
 // Closest hit of a group of primitives: through its second-level hierarchy when it has one, else one by one.
@@ -1189,16 +1237,16 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     unsigned long long n_rays = 0;
     const float4 light0 = sc.lights[0];                                 // count > 0 implies a light; the usual scene has one
 
-    // One sample ray: hard shadows (raytracer.cpp:509-530) or sample j of a soft shadow (raytracer.cpp:534-571).
-    auto sample_unblocked = [&](int node, int cp, int l, int j, const float4 a, const float4 lt) __attribute__((always_inline)) -> bool {
+    // One sample ray: hard shadows (raytracer.cpp:509-530) or sample j of a soft shadow (raytracer.cpp:534-571).  Returns
+    // the distance the reported hit is compared with (the light sample's; -inf for hard shadows: any hit blocks).
+    auto make_sample_ray = [&](int node, int cp, int l, int j, const float4 a, const float4 lt, Ray& sr) __attribute__((always_inline)) -> float {
         const V3 p = mk(a.x, a.y, a.z);
-        Ray sr; sr.time = a.w;
-        Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
+        sr.time = a.w;
         if (MODE == 0) {
             const float4 b = w.n_b[node];
             sr.d = normalise(mk(lt.x - p.x, lt.y - p.y, lt.z - p.z));
             sr.o = p + mk(b.x, b.y, b.z) * 1e-2f;                        // raytracer.cpp:515: unflipped geometric normal
-            return !trace<true, SUB>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
+            return -INFINITY;
         }
         uint32_t path = (uint32_t)f2i(w.n_c[node].z);
         if (cp) path = mix32(path + 0x9E3779B1u * (uint32_t)cp);        // every copy of a hit draws its own samples
@@ -1211,6 +1259,13 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         else { ld = normalise(h2l); lightDist = len_ref(h2l); }
         sr.o = p + ld * 0.001f;                                          // raytracer.cpp:549
         sr.d = ld;
+        return lightDist;
+    };
+    auto sample_unblocked = [&](int node, int cp, int l, int j, const float4 a, const float4 lt) __attribute__((always_inline)) -> bool {
+        Ray sr;
+        Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
+        const float lightDist = make_sample_ray(node, cp, l, j, a, lt, sr);
+        if (MODE == 0) return !trace<true, SUB>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
         // only "closest reported distance < lightDist" is asked for (raytracer.cpp:564)
         const bool hit = trace<false, SUB, FAST>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best, lightDist);
         return !(hit && best.t < lightDist);
@@ -1233,10 +1288,12 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         // pairs are expanded to rays, RT_BLOCK at a time, SS neighbouring lanes per pair, and counted with a ballot.
         // The per-pair work is so done once, not once per sample, and every wavefront that traces is full of rays that
         // need tracing (the workgroup's last one aside).
-        __shared__ int s_q[2 * RT_BLOCK], s_qnode[2 * RT_BLOCK];      // queued pairs: index into `out`; node
-        __shared__ unsigned short s_qcp[2 * RT_BLOCK];                // ... and which of the node's copies (< 4096)
-        __shared__ int s_qn;
-        if (threadIdx.x == 0) s_qn = 0;
+        // (scenes with second-level hierarchies collect more pairs before they trace: see the drain below)
+        constexpr int QCAP = 2 * RT_BLOCK;
+        __shared__ int s_q[QCAP], s_qnode[QCAP];                      // queued pairs: index into `out`; node
+        __shared__ unsigned short s_qcp[QCAP];                        // ... and which of the node's copies (< 4096)
+        __shared__ int s_qn, s_next;
+        if (threadIdx.x == 0) { s_qn = 0; s_next = 0; }
         __syncthreads();
         const int pairs_per_pass = RT_BLOCK >> ss_shift;
         for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
@@ -1263,7 +1320,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                     else if (!SUB && MODE != 0 && cull &&
                              !cone_may_hit(sc, f.motion_blur != 0, a.w, mk(a.x, a.y, a.z), mk(lt.x, lt.y, lt.z), f.light_radius,
                                            f.cull_own ? (f2i(b.w) & 0x7fffffff) : -1, mk(b.x, b.y, b.z))) out[item] = SS;
-                    else queue = true;
+                    else { queue = true; if (SUB && MODE != 0) out[item] = 0; }      // (the drain below adds the unblocked samples one by one)
                 }
             }
             {
@@ -1277,6 +1334,160 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
             int qn = s_qn;
             __syncthreads();                                             // everyone has read the count before anyone appends again
             const bool last = g + (int)gridDim.x >= n_chunks;
+            if (SUB && MODE != 0) {
+                // (Hard shadows send one ray per pair: a queue's worth of them is two rays per lane, too few for what follows to
+                // pay; they keep the passes below.)
+                // Walks through second-level hierarchies differ widely in length, and a wavefront whose lanes each trace one
+                // ray lasts as long as its longest walk (measured on 10^7 primitives: 26 of 64 lanes busy per step).  So the
+                // queued pairs' rays are not dealt out 256 at a time: once no further chunk of pairs fits the queue (or after
+                // the last chunk) every wavefront runs a loop in which a lane that has finished its ray takes the next one
+                // of the queue at once - one step of a walk per iteration, whatever ray the lane holds.  Unblocked samples
+                // are added to the pair's count with an atomic (the lanes of a pair no longer sit side by side).
+                if ((qn > QCAP - RT_BLOCK || last) && qn > 0) {
+                    // What a lane does next: nothing (no ray), the first-level walk to its next leaf, a record of a leaf's
+                    // hierarchy, or the test of one primitive of a run - by class, so that a pass runs one test for all its
+                    // lanes.  Each kind of work is a branch with its own trip to memory; a wavefront runs a kind when at
+                    // least RT_REFILL_LANES of its lanes wait for it (the others keep their state), or, when no kind has
+                    // that many, the one most lanes wait for.
+                    enum { K_IDLE = 0, K_FIRST = 1, K_STEP = 2, K_PLANE = 3, K_CUBE = 4, K_SPHERE = 5 };
+                    const int n_queued_rays = qn << ss_shift;
+                    const bool mb = f.motion_blur != 0;
+                    const int lane = (int)__lane_id();
+                    const int n_first = sc.n_nodes;
+                    const bool leaf_rule = f.use_bvh != 0;
+                    const DevPrimSet& S = f.use_bvh ? sc.leafset : sc.walkset;
+                    int kind = K_IDLE, it = 0, i = 0;
+                    bool started = false;
+                    Ray sr; sr.o = mk(0, 0, 0); sr.d = mk(0, 0, 1); sr.time = 0.0f;
+                    SubRay q = make_sub_ray(sc, sr);
+                    float lightDist = -INFINITY; V3 rcp = mk(0, 0, 0); bool fast_ok = false;
+                    SubWalk sw; sub_begin(sw, 0, 1, true);
+                    unsigned key[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu }; int4 ev = make_int4(-1, -1, -1, -1); unsigned cand = 0;
+                    bool more = true;                                // (wavefront-uniform) the queue may still hold rays
+                    // a sample is unblocked unless the group that ends the walk reports a hit nearer than the light sample
+                    // (raytracer.cpp:564; any hit for hard shadows, raytracer.cpp:520-529)
+                    auto finish = [&](bool blocked) { if (!blocked) atomicAdd(&out[it], 1); kind = K_IDLE; };
+                    // the walk of a group ended without a hit that decides: a hit at or beyond the light sample ends the
+                    // reference's search too (bvh.cpp:97-101), no hit sends the ray on to its next leaf
+                    auto exhausted = [&]() { if (sw.has || !f.use_bvh) finish(false); else kind = K_FIRST; };
+                    auto pop = [&]() { if (sub_pop(sw, s_stack) == SUB_EXHAUSTED) exhausted(); else kind = K_STEP; };
+                    // the run's next primitive whose box is entered before what still matters, nearest box first
+                    auto next_candidate = [&]() {
+                        for (;;) {
+                            const unsigned m = min(min(key[0], key[1]), min(key[2], key[3]));
+                            if (m == 0xffffffffu || __uint_as_float(m & ~3u) > sw.prune_t) { pop(); return; }
+                            const unsigned k = m & 3u;
+                            key[0] = k == 0u ? 0xffffffffu : key[0]; key[1] = k == 1u ? 0xffffffffu : key[1];
+                            key[2] = k == 2u ? 0xffffffffu : key[2]; key[3] = k == 3u ? 0xffffffffu : key[3];
+                            const unsigned entry = (unsigned)(k == 0u ? ev.x : k == 1u ? ev.y : k == 2u ? ev.z : ev.w);
+                            if (entry == 0xffffffffu) continue;
+                            cand = entry & 0x3fffffffu; kind = K_PLANE + (int)(entry >> 30);
+                            return;
+                        }
+                    };
+                    auto tested = [&](bool ok, float t) {
+                        if (ok && (!leaf_rule || t >= 0.0f) && t < sw.best_t) {
+                            sw.has = true; sw.best_t = t;
+                            if (MODE == 0 || t < lightDist) { finish(true); return; }
+                            sw.prune_t = lightDist;                  // only a hit nearer than the light sample still matters
+                        }
+                        next_candidate();
+                    };
+                    for (;;) {
+                        const int n_idle = __popcll(__ballot(kind == K_IDLE));
+                        if (more && (n_idle >= RT_REFILL_LANES || n_idle == 64)) {
+                            // the idle lanes take the next rays of the queue: one LDS atomic per wavefront
+                            const unsigned long long idle = __ballot(kind == K_IDLE);
+                            const int first_idle = __ffsll((long long)idle) - 1;
+                            int base = 0;
+                            if (lane == first_idle) base = atomicAdd(&s_next, n_idle);
+                            base = __shfl(base, first_idle, 64);
+                            more = base + n_idle < n_queued_rays;
+                            if (kind == K_IDLE) {
+                                const int my = base + __popcll(idle & ((1ull << lane) - 1ull));
+                                if (my < n_queued_rays) {
+                                    const int pr = my >> ss_shift, j = my & (SS - 1);
+                                    it = s_q[pr];
+                                    const int node = s_qnode[pr], cp = (int)s_qcp[pr];
+                                    const int l = (L == 1) ? 0 : it % L;
+                                    ++n_rays;
+                                    lightDist = make_sample_ray(node, cp, l, j, w.n_a[node], (L == 1) ? light0 : sc.lights[l], sr);
+                                    q = make_sub_ray(sc, sr);
+                                    const float ax = fabsf(sr.d.x), ay = fabsf(sr.d.y), az = fabsf(sr.d.z);
+                                    fast_ok = ax > 1e-18f && ax < 1e18f && ay > 1e-18f && ay < 1e18f && az > 1e-18f && az < 1e18f;
+                                    rcp = mk(__builtin_amdgcn_rcpf(sr.d.x), __builtin_amdgcn_rcpf(sr.d.y), __builtin_amdgcn_rcpf(sr.d.z));
+                                    kind = K_FIRST; started = false; i = 0;
+                                }
+                            }
+                        }
+                        const int n1 = __popcll(__ballot(kind == K_FIRST)), n2 = __popcll(__ballot(kind == K_STEP)), n3 = __popcll(__ballot(kind == K_PLANE)),
+                                  n4 = __popcll(__ballot(kind == K_CUBE)), n5 = __popcll(__ballot(kind == K_SPHERE));
+                        const int most = max(max(n1, n2), max(n3, max(n4, n5)));
+                        if (most == 0) { if (!more) break; continue; }      // every ray of this wavefront is done (and the queue empty)
+                        const int need = min(most, RT_REFILL_LANES);
+                        if (n2 >= need && kind == K_STEP) {
+                            unsigned off;
+                            if (sub_boxes<SUB == 2>(sc, sw, sr, q, mb, key, ev, off)) { RT_WS(sc, WS_RUN); next_candidate(); }
+                            else if (sub_descend(sw, key, s_stack) == SUB_EXHAUSTED) exhausted();
+                        }
+                        if (n4 >= need && kind == K_CUBE) {
+                            float t; RT_WS(sc, WS_CUBE);
+                            const bool ok = cube_test<false, FAST>(S.cubes + 6 * cand, sr, mb, false, t, nullptr);
+                            tested(ok, t);
+                        }
+                        if (n5 >= need && kind == K_SPHERE) {
+                            float t; RT_WS(sc, WS_SPHERE);
+                            const bool ok = sphere_test<false, FAST>(S.spheres + 2 * cand, sr, mb, false, t, nullptr);
+                            tested(ok, t);
+                        }
+                        if (n3 >= need && kind == K_PLANE) {
+                            float t; RT_WS(sc, WS_PLANE);
+                            const bool ok = plane_test<false, FAST>(S.planes + 3 * cand, S.edges, nullptr, sr, false, t, nullptr);
+                            tested(ok, t);
+                        }
+                        if (n1 >= need && kind == K_FIRST) {
+                            if (f.use_bvh) {
+                                // on to the next leaf whose box the ray pierces (aabb.cpp:31-63, in the reference's visiting order)
+                                int leaf = -1;
+                                while (i < n_first) {
+                                    const float4 a = s_nodes[2 * i], b = s_nodes[2 * i + 1];
+                                    RT_WS(sc, WS_BOX);
+                                    if (!slab<FAST>(sr, a, b, rcp, fast_ok)) { i = f2i(a.w); continue; }
+                                    ++i;
+                                    leaf = f2i(b.w);
+                                    if (leaf >= 0) break;
+                                }
+                                if (leaf < 0) finish(false);
+                                else {
+                                    const int4 l0 = s_leaves[2 * leaf], l1 = s_leaves[2 * leaf + 1];
+                                    RT_WS(sc, WS_GROUP);
+                                    if (l1.z >= 0) { sub_begin(sw, l1.z, l1.w, true); kind = K_STEP; }
+                                    else {
+                                        Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
+                                        if (test_prims<MODE == 0, FAST>(sc.leafset, sr, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, true, lightDist, best))
+                                            finish(MODE == 0 || best.t < lightDist);
+                                    }
+                                }
+                            } else if (!started) {
+                                // raytracer.cpp:202-256: every primitive of the scene file
+                                started = true;
+                                if (sc.file_sub_root >= 0) { sub_begin(sw, sc.file_sub_root, sc.file_sub_depth, false); kind = K_STEP; }
+                                else {
+                                    const DevPrimSet& FS = sc.walkset;
+                                    Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
+                                    const bool hit = test_prims<MODE == 0, FAST>(FS, sr, mb, 0, FS.n_planes, 0, FS.n_cubes, 0, FS.n_spheres, false, lightDist, best);
+                                    finish(hit && (MODE == 0 || best.t < lightDist));
+                                }
+                            } else finish(false);
+                        }
+                    }
+                    qn = 0;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) { s_qn = qn; s_next = 0; }
+                __syncthreads();
+                continue;
+            }
             while (qn >= pairs_per_pass || (last && qn > 0)) {           // after the last chunk the queue is emptied
                 const int take = min(qn, pairs_per_pass), first = qn - take;
                 const int k = (int)(threadIdx.x >> ss_shift), j = (int)(threadIdx.x & (unsigned)(SS - 1));
@@ -1351,7 +1562,7 @@ DEVI void store_pixel(const DevFrame& f, unsigned char* __restrict__ out, int ti
 // then the parent's combination of its children's colours with both clamps (raytracer.cpp:436-503).  Level 0
 // adds the result to the pixel's running sum (raytracer.cpp:154).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, DevFrame f, DevWork w, int level) {
+__global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(DevScene sc, DevFrame f, DevWork w, int level) {
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
     // chunks of RT_BLOCK hits inside the level's regions, as in k_extend
     __shared__ int s_pre[RT_REGIONS + 1], s_cnt[RT_REGIONS];

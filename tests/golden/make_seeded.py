@@ -9,7 +9,9 @@ binary exists).  Output: seeded.npz
   alleffects_seed1 / _seed2   : cases.ALL_EFFECTS rendered in bands with two different sets of rand() seeds
   alleffects_high             : the same estimators with cases.ALL_EFFECTS_HIGH (256 primary samples per pixel)
   deep_mean_<scene>_<flags>   : float32 mean image over cases.DEEP_GLOSS_SEEDS rand() seeds of cases.DEEP_GLOSS
-Usage: make_seeded.py [floor] [mirror] [banded] [alleffects] [deep]   (default: all; parts not named are kept from the existing file)
+  seedmean_<scene>_<flags>    : float32 mean image over cases.SEED_MEAN_SEEDS rand() seeds (101, 102, ...) of the GPU-side flag
+                                sets of cases.SEED_MEAN: the same estimators, sample count for sample count
+Usage: make_seeded.py [floor] [mirror] [banded] [alleffects] [deep] [seedmean]   (default: all; parts not named are kept from the existing file)
 """
 import sys
 from concurrent.futures import ProcessPoolExecutor
@@ -57,7 +59,7 @@ def banded(ex, scene, flags, seed0=1):
 
 
 def main():
-    parts = set(sys.argv[1:]) or {"floor", "mirror", "banded", "alleffects", "deep"}
+    parts = set(sys.argv[1:]) or {"floor", "mirror", "banded", "alleffects", "deep", "seedmean"}
     path = HERE / "seeded.npz"
     out = dict(np.load(path)) if path.exists() else {}
     with ProcessPoolExecutor(max_workers=int(__import__("os").environ.get("SEEDED_WORKERS", "7"))) as ex:
@@ -89,6 +91,11 @@ def main():
                 imgs = np.stack(list(ex.map(render, [(scene, flags, s) for s in seeds]))).astype(np.float64)
                 out[f"deep_mean_{cases.case_id(scene, flags)}"] = imgs.mean(axis=0).astype(np.float32)
                 out[f"deep_var_{cases.case_id(scene, flags)}"] = imgs.var(axis=0).sum(axis=2).astype(np.float32)
+        if "seedmean" in parts:
+            for scene, flags, _ in cases.SEED_MEAN:
+                seeds = range(101, 101 + cases.SEED_MEAN_SEEDS)
+                imgs = np.stack(list(ex.map(render, [(scene, flags, s) for s in seeds]))).astype(np.float64)
+                out[f"seedmean_{cases.case_id(scene, flags)}"] = imgs.mean(axis=0).astype(np.float32)
     np.savez_compressed(path, **out)
     for k, v in out.items():
         print(k, v.shape, v.dtype)

@@ -127,12 +127,20 @@ def test_seed_means_match_the_reference_high_sample_renders(scene, flags, golden
     """Glossy reflection combined with soft shadows - every hit of a cone-sampled ray draws its own shadow samples
     (raytracer.cpp:400-413 under :330-332, :534-571; on the device the queue entries of k_extend that are not bundled) -
     and the headline configuration at its own depth (-rd 4 -ss -sss 16: bundles under bundles, the shadow launch that
-    covers levels 1 to 4).  The mean of sixteen renders with different seeds against ONE render of the reference binary
-    with more samples per estimate."""
+    covers levels 1 to 4).  Two comparisons of the mean of sixteen renders with different seeds:
+    (1) with the mean of sixteen renders of the CPU restatement (different rand() seeds; seed 1 of it is the reference
+    binary's image byte for byte) at the SAME flags - the same estimators sample count for sample count: >= 40 dB;
+    (2) with ONE render of the reference binary with more samples per estimate.  That image carries its own noise, and
+    its expectation is not exactly the low-count one (the clamps of raytracer.cpp:342-344, 501-503 are applied to
+    estimates whose spread depends on the counts), so the bar is relative: as close to the binary's image as the
+    restatement's own sixteen-seed mean is, within 1.5 dB - and 40 dB outright where that mean reaches it."""
     imgs, st = render_seeds(scene, flags, range(1, cases.SEED_MEAN_SEEDS + 1), textures_dir)
     mean = imgs.astype(np.float64).mean(axis=0)
-    p = psnr(mean, STO[cases.case_id(scene, golden_flags)])
-    assert p >= 40.0, f"PSNR {p:.1f} dB"
+    rest = SEEDED[f"seedmean_{cases.case_id(scene, flags)}"].astype(np.float64)
+    gold = STO[cases.case_id(scene, golden_flags)]
+    p_rest, p_gold, p_ref = psnr(mean, rest), psnr(mean, gold), psnr(rest, gold)
+    assert p_rest >= 40.0, f"GPU mean vs restatement mean: {p_rest:.1f} dB"
+    assert p_gold >= min(40.0, p_ref) - 1.5, f"GPU mean vs reference render: {p_gold:.1f} dB; restatement mean vs reference render: {p_ref:.1f} dB"
     assert st.shadow_rays > 0 and st.reflection_rays > 0
 
 

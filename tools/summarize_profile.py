@@ -59,7 +59,12 @@ for k, c in traffic.items():
     out[k] = rec
 # the form bench.py reads as profiles/counters_latest.json: {workload: {"source": ..., "kernels": {kernel: per-launch averages}}}
 workload = sys.argv[2] if len(sys.argv) > 2 else "config2"
-wrapped = {workload: {"source": "tools/profile.sh (rocprofv3 --pmc, one counter group per pass; FETCH_SIZE doubled for gfx950, FETCH_SIZE and "
+import datetime
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import bench
+wrapped = {workload: {"kernel_sources_sha": bench.kernel_sources_sha(), "collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
+                      "source": "tools/profile.sh (rocprofv3 --pmc, one counter group per pass; FETCH_SIZE doubled for gfx950, FETCH_SIZE and "
                                 "WRITE_SIZE x1024; one frame at a time, library options overlap=0,graphs=0); values are averages per launch",
                       "kernels": out}}
 json.dump(wrapped, open(f"{root}/counters.json", "w"), indent=1)
