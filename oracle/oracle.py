@@ -45,6 +45,8 @@ def lib():
         L.orc_last_error.restype = C.c_char_p
         L.orc_set_window.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_set_window.restype = None
+        L.orc_set_stride.argtypes = [C.c_int, C.c_int]
+        L.orc_set_stride.restype = None
         _lib = L
     return _lib
 
@@ -58,15 +60,17 @@ def parse_args(flags: list[str]) -> OrcConfig:
     return cfg
 
 
-def render(scene_text: str, flags: list[str], textures_dir: str | None = None, rand_seed: int = 1, window=None):
+def render(scene_text: str, flags: list[str], textures_dir: str | None = None, rand_seed: int = 1, window=None, stride=(1, 1)):
     """Returns (image int32 [H,W,3], OrcStats). rand_seed=1 is the state of a process that never called srand.
-    window = (x0, y0, x1, y1): render only those pixels (exact for deterministic flag sets), the rest stays 0."""
+    window = (x0, y0, x1, y1): render only those pixels (exact for deterministic flag sets), the rest stays 0;
+    stride = (sx, sy): of those, only every sx-th column and sy-th row counted from the window's corner."""
     from ref_runner import get_resolution  # same directory
     w, h = get_resolution(scene_text)
     cfg = parse_args(flags)
     out = np.zeros(w * h * 3, dtype=np.int32)
     W, H = C.c_int(), C.c_int()
     st = OrcStats()
+    lib().orc_set_stride(int(stride[0]), int(stride[1]))
     if window is not None:
         lib().orc_set_window(*[int(v) for v in window])
     else:

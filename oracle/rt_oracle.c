@@ -135,6 +135,10 @@ static orc_stats* g_stats;
  * deterministic flag sets a pixel's value does not depend on the others, so a window is an exact crop. */
 static int g_win[4] = { 0, 0, 1 << 30, 1 << 30 };
 void orc_set_window(int x0, int y0, int x1, int y1) { g_win[0] = x0; g_win[1] = y0; g_win[2] = x1; g_win[3] = y1; }
+/* Inside the window only every sx-th column and sy-th row (from the window's corner) is rendered: a sparse sample of a
+ * frame that is out of reach as a whole.  Exact for deterministic flag sets (no pixel depends on another). */
+static int g_stride[2] = { 1, 1 };
+void orc_set_stride(int sx, int sy) { g_stride[0] = sx > 0 ? sx : 1; g_stride[1] = sy > 0 ? sy : 1; }
 
 /* ------------------------------------------------------------------------------------------------
  * Vector helpers (raytracer.cpp:577-631, 671-673)
@@ -1161,6 +1165,7 @@ int orc_render(const char* scene_text, const char* textures_dir, const orc_confi
     for (int y = 0; y < cam->res_y; ++y) {
         for (int x = 0; x < cam->res_x; ++x) {
             if (x < g_win[0] || x >= g_win[2] || y < g_win[1] || y >= g_win[3]) continue;
+            if ((x - g_win[0]) % g_stride[0] != 0 || (y - g_win[1]) % g_stride[1] != 0) continue;
             float pc[3] = { 0.0f, 0.0f, 0.0f };
             float u, v;
             for (int s = 0; s < AA; ++s) {

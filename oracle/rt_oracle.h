@@ -56,6 +56,7 @@ int orc_render(const char* scene_text, const char* textures_dir, const orc_confi
 /* Restrict the following orc_render calls to the pixel window [x0,x1) x [y0,y1) (others stay 0). An exact crop for
  * deterministic flag sets only. orc_set_window(0, 0, 1 << 30, 1 << 30) restores the full frame. */
 void orc_set_window(int x0, int y0, int x1, int y1);
+void orc_set_stride(int sx, int sy);   /* inside the window, only every sx-th column / sy-th row */
 
 /* Known-answer helpers (same parsing + build as orc_render). */
 /* Camera::convertPixelToRay, camera.cpp:109-199, with aperture 0 (no lens sample). out6 = origin, direction. */

@@ -1164,11 +1164,16 @@ DEVI bool cone_may_hit(const DevScene& sc, bool mb, float time, V3 p, V3 lc, flo
         bool ruled_out = false;
         if (nl2 > 1e-20f && nl2 < 1e20f) {
             const float inl = __builtin_amdgcn_rsqf(nl2);
-            float na = dot(n, a) * inl, h = dot(n, mk(w1.x - p.x, w1.y - p.y, w1.z - p.z)) * inl;   // signed distance of the plane ahead of p
-            if (na < 0.0f) { na = -na; h = -h; }
+            // signed distance of the plane ahead of p, measured to both vertices an offset may come from: the winding-sorted
+            // first vertex (this record, what -u tests) and the file-order first vertex (third word; what the leaves' copies
+            // test, plane.cpp:149 on bvh.cpp's copies).  They lie in one plane only for a planar polygon.
+            const float4 w2 = S.planes[3 * i + 2];
+            float na = dot(n, a) * inl, h = dot(n, mk(w1.x - p.x, w1.y - p.y, w1.z - p.z)) * inl, h2 = dot(n, mk(w2.y - p.x, w2.z - p.y, w2.w - p.z)) * inl;
+            if (na < 0.0f) { na = -na; h = -h; h2 = -h2; }
             const float least = na * cos_t - __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - na * na)) * sin_t;    // smallest n.d over the cone
-            const float scale = fmaxf(fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fmaxf(fabsf(p.z), 1.0f)), fmaxf(fmaxf(fabsf(w1.x), fabsf(w1.y)), fabsf(w1.z)));
-            ruled_out = least > 0.2f && h < 1e-4f - 2e-6f * scale;      // 0.001 x 0.2 of head start against the rounding of h
+            const float scale = fmaxf(fmaxf(fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fmaxf(fabsf(p.z), 1.0f)), fmaxf(fmaxf(fabsf(w1.x), fabsf(w1.y)), fabsf(w1.z))),
+                                      fmaxf(fmaxf(fabsf(w2.y), fabsf(w2.z)), fabsf(w2.w)));
+            ruled_out = least > 0.2f && fmaxf(h, h2) < 1e-4f - 2e-6f * scale;      // 0.001 x 0.2 of head start against the rounding of h
         }
         if (ruled_out) continue;
         const float4 bs = sc.plane_bound[i];
@@ -1293,7 +1298,9 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         __shared__ int s_q[QCAP], s_qnode[QCAP];                      // queued pairs: index into `out`; node
         __shared__ unsigned short s_qcp[QCAP];                        // ... and which of the node's copies (< 4096)
         __shared__ int s_qn, s_next;
+        __shared__ unsigned s_qcnt[SUB ? QCAP / 2 : 1];              // the drain's unblocked samples per queued pair, 16 bits each
         if (threadIdx.x == 0) { s_qn = 0; s_next = 0; }
+        if (SUB) for (int k = threadIdx.x; k < QCAP / 2; k += blockDim.x) s_qcnt[k] = 0u;
         __syncthreads();
         const int pairs_per_pass = RT_BLOCK >> ss_shift;
         for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
@@ -1320,7 +1327,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                     else if (!SUB && MODE != 0 && cull &&
                              !cone_may_hit(sc, f.motion_blur != 0, a.w, mk(a.x, a.y, a.z), mk(lt.x, lt.y, lt.z), f.light_radius,
                                            f.cull_own ? (f2i(b.w) & 0x7fffffff) : -1, mk(b.x, b.y, b.z))) out[item] = SS;
-                    else { queue = true; if (SUB && MODE != 0) out[item] = 0; }      // (the drain below adds the unblocked samples one by one)
+                    else queue = true;
                 }
             }
             {
@@ -1356,7 +1363,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                     const int n_first = sc.n_nodes;
                     const bool leaf_rule = f.use_bvh != 0;
                     const DevPrimSet& S = f.use_bvh ? sc.leafset : sc.walkset;
-                    int kind = K_IDLE, it = 0, i = 0;
+                    int kind = K_IDLE, pr = 0, i = 0;
                     bool started = false;
                     Ray sr; sr.o = mk(0, 0, 0); sr.d = mk(0, 0, 1); sr.time = 0.0f;
                     SubRay q = make_sub_ray(sc, sr);
@@ -1366,7 +1373,9 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                     bool more = true;                                // (wavefront-uniform) the queue may still hold rays
                     // a sample is unblocked unless the group that ends the walk reports a hit nearer than the light sample
                     // (raytracer.cpp:564; any hit for hard shadows, raytracer.cpp:520-529)
-                    auto finish = [&](bool blocked) { if (!blocked) atomicAdd(&out[it], 1); kind = K_IDLE; };
+                    // (counted in LDS: an atomic on the pair's count in memory would stand, in the wavefront's in-order memory
+                    // counter, before the loads of its next step)
+                    auto finish = [&](bool blocked) { if (!blocked) atomicAdd(&s_qcnt[pr >> 1], 1u << (16 * (pr & 1))); kind = K_IDLE; };
                     // the walk of a group ended without a hit that decides: a hit at or beyond the light sample ends the
                     // reference's search too (bvh.cpp:97-101), no hit sends the ray on to its next leaf
                     auto exhausted = [&]() { if (sw.has || !f.use_bvh) finish(false); else kind = K_FIRST; };
@@ -1406,8 +1415,8 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                             if (kind == K_IDLE) {
                                 const int my = base + __popcll(idle & ((1ull << lane) - 1ull));
                                 if (my < n_queued_rays) {
-                                    const int pr = my >> ss_shift, j = my & (SS - 1);
-                                    it = s_q[pr];
+                                    pr = my >> ss_shift;
+                                    const int j = my & (SS - 1), it = s_q[pr];
                                     const int node = s_qnode[pr], cp = (int)s_qcp[pr];
                                     const int l = (L == 1) ? 0 : it % L;
                                     ++n_rays;
@@ -1481,6 +1490,11 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                             } else finish(false);
                         }
                     }
+                    // every wavefront's rays are done: the pairs' counts go to memory, and the accumulators back to zero
+                    __syncthreads();
+                    for (int k = threadIdx.x; k < qn; k += blockDim.x) out[s_q[k]] = (int)((s_qcnt[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+                    __syncthreads();
+                    for (int k = threadIdx.x; k < (qn + 1) / 2; k += blockDim.x) s_qcnt[k] = 0u;
                     qn = 0;
                 }
                 __syncthreads();

@@ -21,7 +21,7 @@ __host__ __device__ inline size_t rt_sub_motion_offset(int h) {
 #define RT_MAX_LDS_LEAVES  512       // leaf records staged in LDS (32 B each)
 #define RT_SUB_LEAF        4         // second-level hierarchy: primitives per entry run
 #define RT_SUB_MIN_GROUP   8         // groups of at most this many primitives are tested one by one
-#define RT_SUB_STACK       44        // most second-level traversal stack entries per thread (LDS); see rt_sub_stack_entries
+#define RT_SUB_STACK       40        // most second-level traversal stack entries per thread (LDS); see rt_sub_stack_entries
 #define RT_SUB_MAX_DEPTH   24        // deepest second-level hierarchy (16M runs)
 
 // ---- primitives ---------------------------------------------------------------------------------------
@@ -183,10 +183,10 @@ static inline int rt_lds_prim_words(const DevScene& sc) {
            2 * (sc.fileset.n_spheres + sc.leafset.n_spheres) + 3 * (sc.fileset.n_planes + sc.fileset.n_cubes + sc.fileset.n_spheres);
 }
 
-// Stack entries a walk of a hierarchy of `depth` levels needs: a step (two binary levels, or the step from the last
-// level to the runs) pushes up to three siblings, and there are ceil(depth / 2) + 1 steps on a path from the root to a
-// primitive.
-static inline int rt_sub_stack_entries(int depth) { return 3 * ((depth + 1) / 2 + 1) + 2; }
+// Stack entries a walk of a hierarchy of `depth` levels needs: a step on a record above the runs (two binary levels, or
+// the step from the last level to the runs) pushes up to three siblings, a run's record pushes nothing, and there are
+// ceil(depth / 2) records above the runs on a path from the root to a primitive.
+static inline int rt_sub_stack_entries(int depth) { return 3 * ((depth + 1) / 2) + 2; }
 
 // kernel launchers (rt_kernels.hip)
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);

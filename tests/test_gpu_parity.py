@@ -446,6 +446,45 @@ def test_large_scene_windows_match_oracle(moving):
     ls.close()
 
 
+def test_million_primitive_frame_matches_the_oracle_on_a_pixel_grid():
+    """The large-scene configuration at its own size: 10^6 random primitives (seed 42) at 1920x1080, BVH and -u.  Every
+    40th pixel of every 40th row of the CPU restatement's frame - 1296 pixels over as many different primitives - is
+    committed as a fixture (tests/golden/make_windows.py: a quarter of an hour and 9 GB on the host, which is why it is
+    not rendered here); the frame goes through the second-level hierarchies (thousands of primitives per leaf of the
+    reference's depth-8 tree) and the one-kernel frame path."""
+    grid = np.load(cases.GOLDEN / "windows_1m.npz")
+    n, res = 1_000_000, (1920, 1080)
+    ls = api.ArrayScene(sg.random_prims(n, 42), res)
+    for flags, tag in (([], "bvh"), (["-u"], "u")):
+        cfg, _ = api.parse_args(flags)
+        r = api.Renderer(0); r.upload(ls, with_bvh=bool(cfg.bvh))
+        img, st = r.render(cfg); r.close()
+        assert st.primary_rays == res[0] * res[1]
+        ref = grid[f"grid_{tag}"]
+        got = img[20::40, 20::40].astype(np.int32)
+        assert got.shape == ref.shape and len(np.unique(ref.reshape(-1, 3), axis=0)) > 100
+        assert np.array_equal(got, ref), f"{flags}: {(got != ref).any(axis=2).sum()} of {ref.shape[0] * ref.shape[1]} sampled pixels differ"
+    ls.close()
+
+
+@pytest.mark.parametrize("flags", [[], ["-u"], ["-rd", "2", "-grs", "1"]])
+def test_second_level_hierarchy_changes_no_pixel_at_a_million_primitives(flags):
+    """second_level_min_group on / off at 10^6 primitives on a 160x90 film: the plain search tests the thousands of
+    primitives of every pierced leaf (all 10^6 with -u) one by one, as bvh.cpp:65-95 and raytracer.cpp:202-247 do."""
+    table = sg.random_prims(1_000_000, 42, transparent_frac=0.1)
+    cfg, _ = api.parse_args(flags)
+    got = []
+    for min_group in (8, 1 << 40):
+        ls = api.ArrayScene(table, (160, 90))
+        r = api.Renderer(0)
+        r.set_option("second_level_min_group", min_group)
+        r.upload(ls, with_bvh=bool(cfg.bvh))
+        img, st = r.render(cfg)
+        got.append((img, (st.shadow_rays, st.reflection_rays, st.refraction_rays))); r.close(); ls.close()
+    assert got[0][0].max() > 0
+    assert np.array_equal(got[0][0], got[1][0]) and got[0][1] == got[1][1]
+
+
 def test_randomised_scenes_and_flags_match_oracle(textures_dir):
     """80 random small scenes (all primitive classes, tilted shuffled n-gons, transparency, several lights, textures,
     moving objects) x random deterministic flag sets: images bit-exact, reference-equivalent ray counts equal."""

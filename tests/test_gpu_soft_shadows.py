@@ -298,3 +298,34 @@ def test_untraced_soft_shadow_cones_change_no_pixel_on_random_small_scenes(textu
         assert got[0][1].shadow_rays_ref == got[1][1].shadow_rays_ref
         traced_on += got[0][1].shadow_rays; traced_off += got[1][1].shadow_rays
     assert traced_on < 0.7 * traced_off
+
+
+def test_untraced_soft_shadow_cones_with_polygons_that_are_not_planar(textures_dir):
+    """A polygon's normal comes from its first three vertices in file order (plane.cpp:303-321) and its offset from its
+    first vertex - the winding-sorted one in the reference's own vector, the file-order one in the copies the leaves hold
+    (plane.cpp:149 on bvh.cpp:113's copies).  For a quad whose fourth corner is lifted out of the plane of the other
+    three those are different planes, and the rule that leaves a polygon out of the cone search ("every sample ray starts
+    beyond its plane and moves away") has to hold for both.  Frames with and without the rule must agree, BVH and -u."""
+    rng = np.random.default_rng(77)
+    for k in range(12):
+        lift = float(rng.uniform(0.3, 1.5)) * (1 if k % 2 else -1)
+        quad = [(-2.0, 1.0, 1.2), (2.0, 1.2, 1.2), (-2.2, 4.0, 1.2 + lift), (2.0, 4.2, 1.2)]
+        order = rng.permutation(4)
+        cams = [sg.camera((rng.uniform(-1, 1), -9.0, rng.uniform(1.5, 4.0)), (0.0, 1.0, -0.2), res=(160, 90))]
+        lights = [sg.light((rng.uniform(-4, 4), rng.uniform(-2, 3), rng.uniform(4, 8)), 900.0)]
+        planes = [sg.ground(16.0, 0.0, sg.material((0.6, 0.6, 0.6), (0.1, 0.1, 0.1), 20.0)),
+                  sg.plane([quad[i] for i in order], sg.material((0.8, 0.3, 0.2), (0.2, 0.2, 0.2), 40.0))]
+        spheres = [sg.sphere((rng.uniform(-2, 2), rng.uniform(0, 3), 0.5), 0.5, sg.material((0.2, 0.4, 0.9), (0.0, 0.0, 0.0), 10.0))]
+        text = sg.scene_text(cams, lights, spheres, [], planes)
+        for flags in (["-ss", "-sss", "16"], ["-ss", "-sss", "16", "-u"], ["-ss", "-sss", "4", "-r"]):
+            cfg, _ = api.parse_args(flags); cfg.seed = 300 + k
+            ls = api.LoadedScene(text, cfg, textures_dir)
+            got = []
+            for cull in (1, 0):
+                r = api.Renderer(0); r.set_option("cull_cones", cull)
+                r.upload(ls, with_bvh=bool(cfg.bvh))
+                got.append(r.render(cfg)); r.close()
+            ls.close()
+            assert got[0][0].max() > 0
+            assert np.array_equal(got[0][0], got[1][0]), f"case {k} flags {flags}: {(got[0][0] != got[1][0]).any(axis=2).sum()} pixels differ"
+            assert got[0][1].shadow_rays < got[1][1].shadow_rays
