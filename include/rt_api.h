@@ -206,6 +206,13 @@ void* rt_get_stream(rt_ctx* ctx);
  * unblocked whatever the random numbers, so frames are identical; rt_stats.shadow_rays counts traced rays).
  * "cull_own" = 0/1 (with cull_cones): whether a sphere or cube is left out of that search for sample rays that all leave
  * its own surface outwards (a convex primitive cannot be met again; default 1, frames identical).
+ * "cull_umbra" = 0/1 (with cull_cones): whether the sample rays of a pair are also left untraced when the whole cone passes
+ * well inside one sphere or cube at rest that lies clearly before the light ball and that the search is certain to
+ * get to (default 1; every sample is then blocked whatever the random numbers, raytracer.cpp:564, so frames are identical).
+ * "shadow_queue" = 0/1 (with cull_cones): whether the pairs that do need tracing are handed, through a queue in device
+ * memory, to a launch of their own that deals them out evenly, instead of being traced by the workgroup that met them
+ * (default 1; "grid_shadow_drain" = that launch's workgroups).  "shadow_streams" = 1/2 (with overlap): how many recursion
+ * levels' shadow rays run on internal streams of their own, level 0 or levels 0 and 1 (default 2).
  * "hierarchy_order" = 0/1 (before rt_upload_scene): whether the records of groups with a second-level hierarchy are
  * stored in hierarchy order, a run's primitives side by side (default 1; the reference's testing order, which decides
  * exact ties, is kept per entry).  "sort_rays" = 0/1 and "sort_rays_min_prims" = N: whether the secondary rays of scenes
@@ -216,7 +223,7 @@ void* rt_get_stream(rt_ctx* ctx);
  * frames and statistics identical.
  * "count_rays" = 0/1: whether rt_render_device with a statistics pointer counts rays (default 1) or only times the
  * stages, with the kernels plain frames use (the ray counts then read 0).
- * "max_grid" (all kernels) or "grid_primary" / "grid_secondary" / "grid_shadow" / "grid_shade" = workgroups per launch,
+ * "max_grid" (all kernels) or "grid_primary" / "grid_secondary" / "grid_shadow" / "grid_shadow_drain" / "grid_shade" = workgroups per launch,
  * 0 = chosen per launch (default).  The one switch that does move rendered values, and only those
  * of soft-shadow renders, within their sampling noise: "fast_samples" = 0/1, whether the randomly drawn soft-shadow
  * sample rays are tested with hardware reciprocals (1 ulp) instead of IEEE division; default 1, 0 = the reference's

@@ -215,9 +215,12 @@ struct rt_ctx {
     bool skip_unlit = true;                  // see k_shadow: shadow rays whose result is multiplied by zero are not traced
     bool count_rays = true;                  // frames with statistics count rays (off: stage times only, at the speed of plain frames)
     // 0 = chosen per launch (see enqueue_frame)
-    int grid_primary = 0, grid_secondary = 0, grid_shadow = 0, grid_shade = 0;
+    int grid_primary = 0, grid_secondary = 0, grid_shadow = 0, grid_shade = 0, grid_shadow_drain = 0;
     bool cull_cones = true;                  // see k_shadow: soft-shadow cones that miss every primitive are not traced
     bool fuse_simple = true;                 // frames without recursion and with hard shadows: trace, shadow and shade in one kernel
+    int shadow_queue_rcap = 0;               // (tests) entries per region of such a queue instead of the planned number
+    bool shadow_queue = true;                // ... and the pairs that do need tracing go through a queue in memory to a launch of their own
+    bool cull_umbra = true;                  // ... and pairs whose whole cone of sample rays is certain to be blocked
     bool cull_own = true;                    // ... where a sphere or cube is left out for the rays that leave its own surface outwards
     bool bundle_reflections = true;          // ... as one traced ray with gr_samples hit records (off: gr_samples traced rays)
     bool replicate_reflections = true;       // soft shadows: first reflections traced gr_samples times, each with its own shadow samples
@@ -266,6 +269,7 @@ struct rt_ctx {
     DevBuf<float2> n_uv;
     DevBuf<int> n_pix, link, ctr;
     DevBuf<float> shadow;
+    DevBuf<int4> sq;                         // queues of (hit, light) pairs to trace, see DevWork::sq
     DevBuf<unsigned long long> stats;
     DevBuf<unsigned char> out_tmp;
     unsigned long long last_batches = 0;
@@ -280,8 +284,9 @@ struct rt_ctx {
     int use_graphs = 1;
     // Second stream on which the shadow rays of the primary hits run while the render stream traces the deeper
     // recursion levels (fork and join through the two events; works the same under graph capture).
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux_stream = nullptr, aux_stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
+    int shadow_streams = 2;                   // forked shadow launches of a frame with recursion: level 0 (1) and level 1 (2)
     int overlap = 1;
     int walk_stats = 0;                      // development: kernels built with RT_WALK_STATS count their steps (rt_debug_walk_stats)
     void drop_graphs() {
@@ -340,6 +345,9 @@ rt_ctx* rt_create(int device_id, uint64_t workspace_bytes) {
     e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming);
     if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); rt_destroy(c); return nullptr; }
     return c;
 }
@@ -352,6 +360,9 @@ void rt_destroy(rt_ctx* c) {
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux_stream2) { (void)hipStreamSynchronize(c->aux_stream2); (void)hipStreamDestroy(c->aux_stream2); }
+    if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
+    if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
     DevBuf<float4>* f4s[] = { &c->d_nodes, &c->d_mats, &c->d_plane_uv, &c->d_plane_bound, &c->d_texels, &c->d_lights, &c->d_verts, &c->d_edges, &c->d_file_planes,
                               &c->d_file_cubes, &c->d_file_spheres, &c->d_leaf_planes, &c->d_leaf_cubes, &c->d_leaf_spheres,
                               &c->q_a[0], &c->q_a[1], &c->q_b[0], &c->q_b[1], &c->n_a, &c->n_b, &c->n_c, &c->n_col, &c->accum };
@@ -362,7 +373,7 @@ void rt_destroy(rt_ctx* c) {
     c->sort_temp.release();
     c->d_sub_order_file.release(); c->d_sub_order.release(); c->d_walk_planes.release(); c->d_walk_cubes.release(); c->d_walk_spheres.release();
     c->d_leaves.release(); c->d_tex_desc.release(); c->d_local_tiles.release(); c->n_uv.release(); c->n_pix.release();
-    c->link.release(); c->ctr.release(); c->shadow.release(); c->stats.release(); c->out_tmp.release();
+    c->link.release(); c->ctr.release(); c->shadow.release(); c->sq.release(); c->stats.release(); c->out_tmp.release();
     for (auto& b : c->adopted_arrays) b.release();
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     c->drop_graphs();
@@ -398,7 +409,8 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     }
     if (std::strncmp(name, "grid_", 5) == 0) {
         int* which = std::strcmp(name, "grid_primary") == 0 ? &c->grid_primary : std::strcmp(name, "grid_secondary") == 0 ? &c->grid_secondary :
-                     std::strcmp(name, "grid_shadow") == 0 ? &c->grid_shadow : std::strcmp(name, "grid_shade") == 0 ? &c->grid_shade : nullptr;
+                     std::strcmp(name, "grid_shadow") == 0 ? &c->grid_shadow : std::strcmp(name, "grid_shade") == 0 ? &c->grid_shade :
+                     std::strcmp(name, "grid_shadow_drain") == 0 ? &c->grid_shadow_drain : nullptr;
         if (!which) return c->fail(RT_ERR_ARG, "unknown option %s", name);
         if (value < 0 || value > (1 << 20)) return c->fail(RT_ERR_ARG, "%s must be 0..%d", name, 1 << 20);
         *which = (int)value; c->drop_graphs(); return RT_OK;
@@ -408,10 +420,14 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "fast_samples") == 0) { c->fast_samples = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "cull_cones") == 0) { c->cull_cones = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "fuse_simple") == 0) { c->fuse_simple = value != 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "shadow_queue_rcap") == 0) { c->shadow_queue_rcap = value > 0 ? (int)std::min<long long>(value, 1 << 24) : 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "shadow_queue") == 0) { c->shadow_queue = value != 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "cull_umbra") == 0) { c->cull_umbra = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "cull_own") == 0) { c->cull_own = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "bundle_reflections") == 0) { c->bundle_reflections = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "replicate_reflections") == 0) { c->replicate_reflections = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "overlap") == 0) { c->overlap = value != 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "shadow_streams") == 0) { c->shadow_streams = value >= 2 ? 2 : 1; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "walk_stats") == 0) { c->walk_stats = value != 0; c->drop_graphs(); return RT_OK; }
     return c->fail(RT_ERR_ARG, "unknown option %s", name);
 }
@@ -1225,6 +1241,8 @@ struct WorkPlan {
     long long node_off[RT_MAX_LEVELS + 2], link_off[RT_MAX_LEVELS + 2], rcap[RT_MAX_LEVELS + 2];
     long long slot_off[RT_MAX_LEVELS + 2], slot_mul[RT_MAX_LEVELS + 2];    // per-copy data (colours, shadow counts), see rt_types.h
     size_t cap_nodes = 0, cap_slots = 0, cap_links = 0, cap_rays = 0, cap_pix = 0, cap_shadow = 0;
+    bool shadow_queue = false;             // soft shadows of a tiny scene: pairs to trace go through queues in memory (DevWork::sq)
+    size_t cap_sq = 0; long long sq_rcap = 0;
     long long widest_chunks[RT_MAX_LEVELS + 2];
 };
 
@@ -1232,7 +1250,7 @@ struct WorkPlan {
 static size_t plan_bytes(const WorkPlan& p, bool textures) {
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     return 4 * al(p.cap_rays * 16) + 3 * al(p.cap_nodes * 16) + al(p.cap_slots * 16) + (textures ? al(p.cap_nodes * 8) : 0) + al(p.cap_pix * 4) +
-           al(p.cap_shadow * 4) + al(p.cap_links * 4);
+           al(p.cap_shadow * 4) + al(p.cap_links * 4) + (p.cap_sq ? al(p.cap_sq * 16) : 0);
 }
 
 static int make_plan(rt_ctx* c, const rt_config* cfg, int D, int L, bool textures, long long n_slots, unsigned long long budget, WorkPlan& p) {
@@ -1258,7 +1276,8 @@ static int make_plan(rt_ctx* c, const rt_config* cfg, int D, int L, bool texture
     for (int d = 0; d <= D; ++d) { nodes_per += npp[d]; slots_per += npp[d] * spn[d]; widest = std::max(widest, npp[d]); if (!p.fanout) break; }
     const double links_per = nodes_per - 1.0;
     p.grouped = !cfg->soft_shadows || (cfg->ss_samples <= 64 && (cfg->ss_samples & (cfg->ss_samples - 1)) == 0);
-    const double bytes_per = nodes_per * (16.0 * 3 + (textures ? 8 : 0)) + slots_per * (16.0 + 4.0 * std::max(L, 1)) + 4.0 + links_per * 4.0 +
+    p.shadow_queue = cfg->soft_shadows && p.grouped && L > 0 && c->shadow_queue && c->cull_cones && !c->scene.sub_nodes && c->np + c->nc + c->ns <= 8;
+    const double bytes_per = nodes_per * (16.0 * 3 + (textures ? 8 : 0)) + slots_per * (16.0 + (p.shadow_queue ? 10.0 : 4.0) * std::max(L, 1)) + 4.0 + links_per * 4.0 +
                              (p.fanout ? 2.0 * widest * 32.0 : 0.0);
     // (1/64 of the budget covers the rounding of the regions' capacities, see below)
     long long B = (long long)((double)budget * (63.0 / 64.0) / bytes_per);
@@ -1294,6 +1313,11 @@ static int make_plan(rt_ctx* c, const rt_config* cfg, int D, int L, bool texture
         p.cap_rays = p.fanout ? (size_t)(R * widest_rcap) + 64 : 64;
         p.cap_pix = (size_t)(R * p.rcap[0]);                             // n_pix is indexed by the level-0 node
         p.cap_shadow = p.cap_slots * (size_t)std::max(L, 1);
+        // each shadow launch's queue holds an eighth of all pairs (more than are traced in any scene the rules apply to;
+        // what does not fit is traced by the workgroup that met it)
+        p.sq_rcap = p.shadow_queue ? std::max<long long>(256, (((long long)p.cap_shadow / 8 / R) + 255) & ~255ll) : 0;
+        if (p.shadow_queue && c->shadow_queue_rcap) p.sq_rcap = c->shadow_queue_rcap;
+        p.cap_sq = (size_t)(p.sq_rcap * R * RT_SHADOWQ_LAUNCHES);
         // 32-bit indexing inside the kernels: node and link indices, node * lights, and the shadow rays of one region of
         // one level (k_shadow numbers them inside such a segment)
         double widest_segment = 0;
@@ -1376,7 +1400,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     int fb = cfg->fallback; if (fb == 0) fb = 1;
     f.fallback_full = (fb == 1);
     f.light_radius = cfg->light_radius; f.seed = cfg->seed; f.fast_samples = c->fast_samples ? 1 : 0; f.count_stats = count_stats ? 1 : 0; f.skip_unlit = c->skip_unlit ? 1 : 0;
-    f.cull_cones = c->cull_cones ? 1 : 0; f.cull_own = c->cull_own ? 1 : 0;
+    f.cull_cones = c->cull_cones ? 1 : 0; f.cull_own = c->cull_own ? 1 : 0; f.cull_umbra = c->cull_umbra ? 1 : 0;
     f.replicate = (cfg->soft_shadows && c->replicate_reflections) ? 1 : 0;
     // identical reflection rays are traced once and recorded gr_samples times (the packed hit record holds 12-bit copy numbers)
     f.bundle = (f.replicate && !cfg->glossy_reflect && cfg->gr_samples <= 4096 && c->bundle_reflections) ? 1 : 0;
@@ -1449,6 +1473,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         w.n_pix = (int*)take(cap_pix * 4);
         w.shadow = (float*)take(plan.cap_shadow * 4);
         w.link = (int*)take(cap_links * 4);
+        if (plan.cap_sq) w.sq = (int4*)take(plan.cap_sq * 16);
         if ((size_t)(q - arena) > RT_NOALLOC_BYTES) {
             if (took) release_scratch(c);
             return c->fail(RT_ERR_CAPACITY, "rt_render_device_noalloc: work plan exceeds the scratch array");
@@ -1456,13 +1481,14 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     } else {
         const bool grow = cap_nodes > c->n_a.n || plan.cap_slots > c->n_col.n || cap_links > c->link.n || cap_rays > c->q_a[0].n || (size_t)n_slots > c->accum.n ||
                           (f.textures && cap_nodes > c->n_uv.n) || plan.cap_shadow > c->shadow.n || cap_pix > c->n_pix.n ||
-                          (sorting && (cap_rays > c->sort_keys[0].n || sort_temp_bytes > c->sort_temp.n));
+                          (sorting && (cap_rays > c->sort_keys[0].n || sort_temp_bytes > c->sort_temp.n)) || plan.cap_sq > c->sq.n;
         if (grow) {
             // Recorded frames hold the addresses of the buffers that are about to be freed: drop every recording before any
             // reallocation, and wait for the frames still in flight on either stream.
             c->drop_graphs();
             RT_HIP(c, hipStreamSynchronize(s));
             if (c->aux_stream) RT_HIP(c, hipStreamSynchronize(c->aux_stream));
+            if (c->aux_stream2) RT_HIP(c, hipStreamSynchronize(c->aux_stream2));
         }
         for (int q = 0; q < 2; ++q) { RT_HIP(c, c->q_a[q].resize(cap_rays)); RT_HIP(c, c->q_b[q].resize(cap_rays)); }
         RT_HIP(c, c->n_a.resize(cap_nodes)); RT_HIP(c, c->n_b.resize(cap_nodes)); RT_HIP(c, c->n_c.resize(cap_nodes));
@@ -1471,6 +1497,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         RT_HIP(c, c->n_pix.resize(cap_pix));
         RT_HIP(c, c->shadow.resize(plan.cap_shadow));
         RT_HIP(c, c->link.resize(cap_links));
+        if (plan.cap_sq) RT_HIP(c, c->sq.resize(plan.cap_sq));
         if (sorting) {
             for (int q = 0; q < 2; ++q) { RT_HIP(c, c->sort_keys[q].resize(cap_rays)); RT_HIP(c, c->sort_slots[q].resize(cap_rays)); }
             RT_HIP(c, c->sort_temp.resize(sort_temp_bytes));
@@ -1481,7 +1508,9 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         for (int q = 0; q < 2; ++q) { w.q_a[q] = c->q_a[q].p; w.q_b[q] = c->q_b[q].p; }
         w.n_a = c->n_a.p; w.n_b = c->n_b.p; w.n_c = c->n_c.p; w.n_uv = c->n_uv.p; w.n_col = c->n_col.p; w.n_pix = c->n_pix.p;
         w.shadow = c->shadow.p; w.link = c->link.p; w.accum = c->accum.p; w.ctr = c->ctr.p; w.stats = c->stats.p;
+        w.sq = plan.cap_sq ? c->sq.p : nullptr;
     }
+    w.sq_rcap = (int)plan.sq_rcap;
     w.cap_nodes = (unsigned)cap_nodes;
     c->scene.walk_stats = c->walk_stats ? w.stats + RT_S_WALK : nullptr;
     c->last_flag = w.stats + RT_S_ERR;
@@ -1510,6 +1539,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     const bool fused = c->fuse_simple && D == 0 && !cfg->soft_shadows;
     const bool split = L > 0 && D >= 1 && plan.fanout;                 // shadow rays in two launches: level 0, then the rest
     const bool overlap = split && c->overlap && !tm->on;         // stage times are only meaningful on one stream
+    const bool fork1 = overlap && D >= 2 && c->shadow_streams >= 2;
     for (long long begin = 0; begin < n_slots; begin += B) {
         const int count = (int)std::min<long long>(B, n_slots - begin);
         f.pix_begin = (int)begin; f.pix_count = count;
@@ -1525,7 +1555,9 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         const bool sub = c->scene.sub_nodes != nullptr;
         const int g_primary = c->grid_primary ? c->grid_primary : (sub ? 8192 : (c->scene.lds_prims ? 1024 : 2048));   // 1024: a handful of primitives
         const int g_shade = c->grid_shade ? c->grid_shade : 1024;
-        const int g_shadow = c->grid_shadow ? c->grid_shadow : ((!sub && cfg->soft_shadows && c->fast_samples) ? 8192 : 2048);
+        // (with the queue of pairs to trace the classifying launch's chunks cost about the same: one resident generation)
+        const int g_shadow = c->grid_shadow ? c->grid_shadow : (plan.shadow_queue ? 1280 : ((!sub && cfg->soft_shadows && c->fast_samples) ? 8192 : 2048));
+        const int g_drain = c->grid_shadow_drain ? c->grid_shadow_drain : 2048;
         auto g_secondary = [&](int level) {
             if (c->grid_secondary) return c->grid_secondary;
             const long long worst_chunks = (long long)w.regions * w.link_rcap[level] / RT_BLOCK;
@@ -1563,13 +1595,23 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
                     // the primary hits are final: their shadow rays start now, beside the deeper levels' tracing
                     hipStream_t ss = overlap ? c->aux_stream : s;
                     if (overlap) { RT_HIP(c, hipEventRecord(c->ev_fork, s)); RT_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0)); }
-                    tm->begin(ST_SHADOW); rt_launch_shadow(ss, c->scene, f, w, 0, 0, g_shadow); tm->end();
+                    tm->begin(ST_SHADOW); rt_launch_shadow(ss, c->scene, f, w, 0, 0, g_shadow, g_drain); tm->end();
                     if (overlap) RT_HIP(c, hipEventRecord(c->ev_join, c->aux_stream));
                 }
+                if (level == 1 && fork1) {
+                    // so are the first reflections' and refractions' hits, the other large level (the levels below hold a
+                    // few per cent of a frame's hits): the launches that trace those, and the shading of the deep levels,
+                    // wait on memory most of the time and run beside the shadow rays' arithmetic
+                    RT_HIP(c, hipEventRecord(c->ev_fork2, s)); RT_HIP(c, hipStreamWaitEvent(c->aux_stream2, c->ev_fork2, 0));
+                    rt_launch_shadow(c->aux_stream2, c->scene, f, w, 1, 1, g_shadow, g_drain);
+                    RT_HIP(c, hipEventRecord(c->ev_join2, c->aux_stream2));
+                }
             }
-            if (L > 0) { tm->begin(ST_SHADOW); rt_launch_shadow(s, c->scene, f, w, split ? 1 : 0, D, g_shadow); tm->end(); }
+            if (L > 0) { tm->begin(ST_SHADOW); rt_launch_shadow(s, c->scene, f, w, fork1 ? 2 : (split ? 1 : 0), D, g_shadow, g_drain); tm->end(); }
             for (int level = D; level >= 0; --level) {
-                // only the primary hits' shading needs the forked launch; the deeper levels resolve beside it
+                // only the shading of the levels whose shadow rays were forked needs those launches; the deeper levels
+                // resolve beside them
+                if (fork1 && level == 1) RT_HIP(c, hipStreamWaitEvent(s, c->ev_join2, 0));
                 if (overlap && level == 0) RT_HIP(c, hipStreamWaitEvent(s, c->ev_join, 0));
                 tm->begin(ST_SHADE);
                 rt_launch_shade(s, c->scene, f, w, level, level == 0 ? std::max(1, std::min(g_shade, chunks0_batch)) : g_shade);

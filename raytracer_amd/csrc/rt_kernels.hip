@@ -1063,14 +1063,18 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
     }
 }
 
-// Soft shadows of a scene with a handful of primitives: can ANY sample ray of a (hit, light) pair hit anything?  The
-// sample rays start within 0.001 of the hit point p (raytracer.cpp:549) and aim at points of the ball of radius R
-// around the light (raytracer.cpp:541), so their directions lie in the cone around a = (light - p) / D with
-// sin(half angle) = R / D.  A primitive can only be hit if that cone, widened by the angle its bounding sphere
-// (inflated for what the float tests may report outside the geometry, swept over the motion) subtends from p, reaches
-// the direction of its centre; a polygon can also be ruled out when every ray of the cone leaves its plane behind.
-// When nothing can be hit, every sample is unblocked whatever the random numbers are, and none is traced: the counts
-// written are exactly those tracing would give.  Conservative throughout (a "maybe" traces).
+// Soft shadows of a scene with a handful of primitives: what the sample rays of a (hit, light) pair can hit, decided
+// once per pair.  The sample rays lie on lines through the hit point p (they start 0.001 along their own direction,
+// raytracer.cpp:549) and aim at points of the ball of radius R around the light (raytracer.cpp:541), so their
+// directions lie in the cone around a = (light - p) / D with sin(half angle) = R / D.
+//   * MAY: a primitive can only be hit if that cone, widened for what the float tests may report outside the geometry
+//     (and swept over the motion), reaches it; a polygon can also be ruled out when every ray of the cone leaves its
+//     plane behind.  When nothing can be hit, every sample is unblocked whatever the random numbers are.
+//   * SURE: a sphere or cube at rest that every line of the cone pierces well inside, starting clearly outside it and
+//     reaching it clearly before the nearest point a sample may aim at, is reported by every sample ray at a distance
+//     below the sample's (raytracer.cpp:564): when the search is certain to get to it, every sample is blocked.
+// In both cases no ray is traced and the count written is exactly the one tracing would give.  Conservative
+// throughout (a "maybe" traces).
 DEVI bool cone_may_hit_sphere(V3 p, V3 a, float sin_t, float cos_t, V3 c, float r) {
     const V3 v = c - p;
     const float dv2 = dot(v, v);
@@ -1084,6 +1088,22 @@ DEVI bool cone_may_hit_sphere(V3 p, V3 a, float sin_t, float cos_t, V3 c, float 
     return !(cos_tb > 0.0f && cos_g < cos_tb - 1e-3f);
 }
 
+// Every line through p whose direction is within the cone passes the centre c at a distance of at most
+// |c - p| sin(gamma + theta) (gamma: angle between the axis and the centre).  Below 0.98 r, with p clearly outside,
+// sphere.cpp:127-141 finds tca > 0, d2 < r^2 and reports the near root, which is at most |c - o| <= |c - p| + 0.001.
+// `reach` = what a reported distance must stay below: the nearest a light sample can be, less a margin.
+DEVI bool cone_surely_hits_sphere(V3 p, V3 a, float sin_t, float cos_t, V3 c, float r, float reach) {
+    const V3 v = c - p;
+    const float dist = __builtin_amdgcn_sqrtf(dot(v, v));
+    if (!(dist > r * 1.02f + 0.01f) || !(r > 1e-3f) || !(dist < 1e3f * r)) return false;
+    const float cos_g = dot(v, a) / dist;
+    if (!(cos_g > 0.0f)) return false;
+    const float sin_g = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - cos_g * cos_g));
+    const float sin_sum = sin_g * cos_t + cos_g * sin_t, cos_sum = cos_g * cos_t - sin_g * sin_t;
+    if (!(cos_sum > 0.05f)) return false;
+    return dist * sin_sum * 1.001f + 1e-3f < 0.98f * r && dist + 0.002f < reach;
+}
+
 // own_gid, N: the primitive the hit lies on and its geometric normal there (as the hit record holds it).  A sphere or a
 // cube is convex, so a ray that starts on its surface and heads outwards cannot meet it again; in the reference's
 // arithmetic: the sample ray starts at p + 0.001 d (raytracer.cpp:549), so with N.d >= m > 0 over the whole cone
@@ -1094,42 +1114,91 @@ DEVI bool cone_may_hit_sphere(V3 p, V3 a, float sin_t, float cos_t, V3 c, float 
 //   e <= N.d (1e-4 + 0.001 / scale): tmax then never exceeds the test's own threshold of 1e-4 and it reports no hit.
 // Such a primitive is left out of the search below.
 // The same question against a cube itself rather than the sphere around it, in the cube's own frame (cube.cpp:126-168:
-// translate by the location at the ray's time, rotate back, divide by the scale).  A point of a sample ray at distance s
-// from p lies within s sin(theta) of the axis ray p + u a, and s is at most the distance t_max from p to the farthest
-// point of the cube; so a sample ray can only reach the cube - enlarged by eps for what the float test may report
-// outside it - if the axis ray pierces the cube enlarged by eps + t_max sin(theta) on every side.
-DEVI bool cone_may_hit_cube(const float4* __restrict__ rec, bool mb, float time, V3 p, V3 a, float sin_t) {
+// translate by the location at the ray's time, rotate back, divide by the scale; the cube is then [-1, 1]^3 and
+// distances are in units of its half edge).  Take a point X of a sample ray and the plane through X at right angles to
+// the axis: it meets the axis at A = p + u a, and X - A is at right angles to a and at most u tan(theta) long, so along
+// the cube's axis i it measures at most u tan(theta) sqrt(1 - al_i^2) (al: the axis in the cube's frame).  If X lies in
+// the cube enlarged by eps (for what the float test may report outside it), then |pl_i + u al_i| <= 1 + eps +
+// u tan(theta) sqrt(1 - al_i^2) for the three axes i: six linear conditions on u >= 0.  No u satisfies them all: no
+// sample ray reaches the cube.
+// (eps: the test treats a direction component below 1e-5 as zero, which moves a reported point by up to 1e-5 of the
+// distance travelled, and its slab distances carry a few 1e-7 of their size in rounding; taken ten times over.)
+DEVI bool cone_may_hit_cube(const float4* __restrict__ rec, bool mb, float time, V3 p, V3 a, float sin_t, float cos_t) {
     const float4 w0 = rec[0], w1 = rec[1], w4 = rec[4], w5 = rec[5];
     V3 loc = mk(w0.x, w0.y, w0.z);
     if (mb) loc = mk(lerp_ref(w0.x, w1.x, time), lerp_ref(w0.y, w1.y, time), lerp_ref(w0.z, w1.z, time));
     const float inv = fabsf(w1.w);                                       // 1 / scale
-    if (!(inv > 1e-6f && inv < 1e6f)) return true;
+    if (!(inv > 1e-6f && inv < 1e6f) || !(cos_t > 0.1f)) return true;
     const V3 pl = rot_inv(p - loc, w4, w5) * inv, al = rot_inv(a, w4, w5);
     const float dist = __builtin_amdgcn_sqrtf(dot(pl, pl));
-    const float eps = 0.02f + 2e-3f * (dist + 1.0f);
-    const float t_max = dist + 1.7321f * (1.0f + eps) + 0.001f * inv;    // the rays start 0.001 (world units) beyond p
-    const float H = (1.0f + eps + t_max * sin_t) * 1.001f;
-    float tn = 0.0f, tf = INFINITY;                                      // the axis ray: u >= 0
+    const float eps = 2e-3f + 1e-4f * (dist + 1.0f) + 0.002f * inv;      // (the last term: the rays start 0.001 world units beyond p)
+    const float tan_t = sin_t * __builtin_amdgcn_rcpf(cos_t) * 1.002f;
+    const float H = (1.0f + eps) * 1.001f;
+    float lo = 0.0f, hi = (dist + 1.7321f * (1.0f + eps)) * 1.01f;       // no point of the cube is farther from p
     const float pv[3] = { pl.x, pl.y, pl.z }, av[3] = { al.x, al.y, al.z };
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        if (fabsf(av[i]) > 1e-6f) {
-            const float rc = __builtin_amdgcn_rcpf(av[i]);
-            const float t0 = (-H - pv[i]) * rc, t1 = (H - pv[i]) * rc;
-            tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-        } else if (fabsf(pv[i]) > H) return false;                       // parallel to this pair of faces and outside them
+        const float k = tan_t * __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - av[i] * av[i])) + 1e-5f;
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+            // c u <= b
+            const float c = (sg ? -av[i] : av[i]) - k, b = H - (sg ? -pv[i] : pv[i]);
+            if (c > 1e-6f) hi = fminf(hi, b * __builtin_amdgcn_rcpf(c) * (b > 0.0f ? 1.0001f : 0.9999f));
+            else if (c < -1e-6f) lo = fmaxf(lo, b * __builtin_amdgcn_rcpf(c) * (b > 0.0f ? 1.0001f : 0.9999f));
+            else if (b < -1e-3f * (1.0f + hi)) return false;             // |c| tiny: the condition hardly depends on u
+        }
     }
     // (a NaN anywhere makes the comparison false: "may hit")
-    return !(tn > tf * 1.0001f + 1e-4f);
+    return !(lo > hi + 1e-4f);
 }
 
-DEVI bool cone_may_hit(const DevScene& sc, bool mb, float time, V3 p, V3 lc, float R, int own_gid, V3 N) {
+// A cube at rest, in its own frame.  The plane at right angles to the axis at depth u meets every line of the cone
+// within u tan(theta) of the axis point, i.e. within u tan(theta) sqrt(1 - al_i^2) along the cube's axis i.  If for some
+// u that whole disc lies in the cube shrunk to 0.97 - |pl_i + u al_i| + u tan(theta) sqrt(1 - al_i^2) <= 0.97 for the
+// three axes, again six linear conditions - every sample ray passes through a point well inside the cube, so
+// cube.cpp:170-215 finds tmin < tmax.  With p outside the slab of some axis by more than 0.02 half edges the ray needs
+// at least 0.02 of local distance to get in, so tmin > 1e-4 and is what the test reports: at most the distance to that
+// inner point, u / cos(theta) (the direction component on that axis is then far above the 1e-5 below which the test
+// treats the ray as parallel).
+DEVI bool cone_surely_hits_cube(const float4* __restrict__ rec, V3 p, V3 a, float sin_t, float cos_t, float reach) {
+    const float4 w0 = rec[0], w1 = rec[1], w4 = rec[4], w5 = rec[5];
+    const float inv = fabsf(w1.w), scale = fabsf(w0.w);
+    if (!(inv > 1e-3f && inv < 1e3f) || !(cos_t > 0.1f)) return false;
+    const V3 pl = rot_inv(p - mk(w0.x, w0.y, w0.z), w4, w5) * inv, al = rot_inv(a, w4, w5);
+    if (!(fmaxf(fmaxf(fabsf(pl.x), fabsf(pl.y)), fabsf(pl.z)) > 1.02f + 0.002f * inv)) return false;
+    const float tan_t = sin_t * __builtin_amdgcn_rcpf(cos_t) * 1.002f;
+    float lo = 0.0f, hi = 500.0f;
+    const float pv[3] = { pl.x, pl.y, pl.z }, av[3] = { al.x, al.y, al.z };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float k = tan_t * __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - av[i] * av[i])) + 1e-5f;
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+            // c u <= b
+            const float c = (sg ? -av[i] : av[i]) + k, b = 0.97f - (sg ? -pv[i] : pv[i]);
+            if (c > 1e-6f) hi = fminf(hi, b * __builtin_amdgcn_rcpf(c) * (b > 0.0f ? 0.9999f : 1.0001f));
+            else if (c < -1e-6f) lo = fmaxf(lo, b * __builtin_amdgcn_rcpf(c) * (b > 0.0f ? 0.9999f : 1.0001f));
+            else if (!(b > 1e-3f * (1.0f + fabsf(lo)))) return false;
+        }
+    }
+    if (!(lo + 1e-4f < hi)) return false;                                // (NaN: not certain)
+    return (lo + 2e-4f) * __builtin_amdgcn_rcpf(cos_t) * scale * 1.001f + 0.003f < reach;
+}
+
+// Bit g of `may` / `sure`: the primitive with global id g (planes, then cubes, then spheres, each in file order) may
+// be hit by a sample ray / is certain to block every sample ray, if the search gets to it.  At most 32 primitives.
+struct ConeSets { unsigned may, sure; };
+DEVI ConeSets cone_sets(const DevScene& sc, bool mb, float time, V3 p, V3 lc, float R, int own_gid, V3 N, bool want_sure) {
+    ConeSets out; out.may = 0xffffffffu; out.sure = 0u;
     const V3 ax = lc - p;
     const float D2 = dot(ax, ax);
-    if (!(D2 > 4.0f * R * R) || !(D2 < 1e30f)) return true;             // inside or near the light ball: no useful cone
+    if (!(D2 > 4.0f * R * R) || !(D2 < 1e30f)) return out;              // inside or near the light ball: no useful cone
+    out.may = 0u;
     const float invD = __builtin_amdgcn_rsqf(D2);
     const V3 a = ax * invD;
     const float sin_t = R * invD * 1.001f + 1e-4f, cos_t = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - sin_t * sin_t));
+    const float reach = (D2 * invD - R) * 0.999f - 0.01f;                // every light sample is farther than this
+    want_sure = want_sure && !mb;
     const DevPrimSet& S = sc.fileset;
     // smallest N.d over the cone (N is of unit length up to rounding); NaN compares false everywhere below
     const float n_a = dot(N, a);
@@ -1137,15 +1206,19 @@ DEVI bool cone_may_hit(const DevScene& sc, bool mb, float time, V3 p, V3 lc, flo
     const float p_size = fabsf(p.x) + fabsf(p.y) + fabsf(p.z);
     for (int i = 0; i < S.n_spheres; ++i) {
         const float4 w0 = S.spheres[2 * i], w1 = S.spheres[2 * i + 1];
-        if (S.n_planes + S.n_cubes + i == own_gid && out_least > 0.02f && p_size + fabsf(w0.x) + fabsf(w0.y) + fabsf(w0.z) + fabsf(w1.x) + fabsf(w1.y) + fabsf(w1.z) < 1000.0f)
+        const int gid = S.n_planes + S.n_cubes + i;
+        if (gid == own_gid && out_least > 0.02f && p_size + fabsf(w0.x) + fabsf(w0.y) + fabsf(w0.z) + fabsf(w1.x) + fabsf(w1.y) + fabsf(w1.z) < 1000.0f)
             continue;                                                    // the hit's own sphere, every sample ray leaving it
         V3 c = mk(w0.x, w0.y, w0.z); float r = fabsf(w0.w);
         if (mb) { const V3 e = mk(w1.x, w1.y, w1.z); const V3 h = (e - c) * 0.5f; c = c + h; r += __builtin_amdgcn_sqrtf(dot(h, h)) * 1.001f; }
-        if (cone_may_hit_sphere(p, a, sin_t, cos_t, c, r)) return true;
+        if (!cone_may_hit_sphere(p, a, sin_t, cos_t, c, r)) continue;
+        out.may |= 1u << gid;
+        if (want_sure && w0.w > 0.0f && cone_surely_hits_sphere(p, a, sin_t, cos_t, c, r, reach)) out.sure |= 1u << gid;
     }
     for (int i = 0; i < S.n_cubes; ++i) {
         const float4 w0 = S.cubes[6 * i], w1 = S.cubes[6 * i + 1];
-        if (S.n_planes + i == own_gid && out_least > 0.02f && w0.w > 1e-3f) {
+        const int gid = S.n_planes + i;
+        if (gid == own_gid && out_least > 0.02f && w0.w > 1e-3f) {
             // e: 1e-5 (face choice) + rounding of the hit point and the rotations, in units of the cube's half edge, doubled
             const float scale = w0.w;
             const float e = 1.5e-5f + 2.0f * (2e-7f * (p_size + fabsf(w0.x) + fabsf(w0.y) + fabsf(w0.z) + fabsf(w1.x) + fabsf(w1.y) + fabsf(w1.z)) + 1e-6f * scale) / scale;
@@ -1153,7 +1226,9 @@ DEVI bool cone_may_hit(const DevScene& sc, bool mb, float time, V3 p, V3 lc, flo
         }
         V3 c = mk(w0.x, w0.y, w0.z); float r = fabsf(w0.w) * 1.7325f;    // half edge x sqrt(3)
         if (mb) { const V3 e = mk(w1.x, w1.y, w1.z); const V3 h = (e - c) * 0.5f; c = c + h; r += __builtin_amdgcn_sqrtf(dot(h, h)) * 1.001f; }
-        if (cone_may_hit_sphere(p, a, sin_t, cos_t, c, r) && cone_may_hit_cube(S.cubes + 6 * i, mb, time, p, a, sin_t)) return true;
+        if (!(cone_may_hit_sphere(p, a, sin_t, cos_t, c, r) && cone_may_hit_cube(S.cubes + 6 * i, mb, time, p, a, sin_t, cos_t))) continue;
+        out.may |= 1u << gid;
+        if (want_sure && w0.w > 0.0f && cone_surely_hits_cube(S.cubes + 6 * i, p, a, sin_t, cos_t, reach)) out.sure |= 1u << gid;
     }
     for (int i = 0; i < S.n_planes; ++i) {
         const float4 w0 = S.planes[3 * i], w1 = S.planes[3 * i + 1];
@@ -1177,9 +1252,35 @@ DEVI bool cone_may_hit(const DevScene& sc, bool mb, float time, V3 p, V3 lc, flo
         }
         if (ruled_out) continue;
         const float4 bs = sc.plane_bound[i];
-        if (cone_may_hit_sphere(p, a, sin_t, cos_t, mk(bs.x, bs.y, bs.z), bs.w)) return true;
+        if (cone_may_hit_sphere(p, a, sin_t, cos_t, mk(bs.x, bs.y, bs.z), bs.w)) out.may |= 1u << i;
     }
-    return false;
+    return out;
+}
+
+// What a pair's sample rays need: CONE_NONE = nothing can be hit (count SS), CONE_BLOCKED = every one is blocked
+// (count 0), CONE_TRACE = trace them.  Without the BVH a sample is blocked when the closest reported distance over all
+// primitives is below the light sample's (raytracer.cpp:202-256, 564): one certain blocker decides.  With it the
+// reference returns the result of the last leaf that reported anything (bvh.cpp:35-105) - in this walk's order: of
+// the first; so the leaves are taken in that order, and the first one holding anything that may be hit decides: if it
+// holds a certain blocker, the leaf's closest distance is below the light sample's whatever else it holds.  (A ray that
+// passes well inside a primitive passes well inside every box around it: aabb.cpp:31-63 lets it into the leaf.)
+enum { CONE_NONE = 0, CONE_BLOCKED = 1, CONE_TRACE = 2 };
+DEVI int cone_outcome(const DevScene& sc, const float4* __restrict__ nodes, const int4* __restrict__ leaves, bool use_bvh, ConeSets cs) {
+    if (cs.may == 0u) return CONE_NONE;
+    if (cs.sure == 0u) return CONE_TRACE;
+    if (!use_bvh) return CONE_BLOCKED;
+    const DevPrimSet& S = sc.leafset;
+    for (int i = 0; i < sc.n_nodes; ++i) {
+        const int leaf = f2i(nodes[2 * i + 1].w);
+        if (leaf < 0) continue;
+        const int4 l0 = leaves[2 * leaf], l1 = leaves[2 * leaf + 1];
+        unsigned held = 0u;
+        for (int k = l0.x; k < l0.x + l0.y; ++k) held |= 1u << (f2i(S.planes[3 * k + 2].x) & 31);
+        for (int k = l0.z; k < l0.z + l0.w; ++k) held |= 1u << (f2i(S.cubes[6 * k + 3].z) & 31);
+        for (int k = l1.x; k < l1.x + l1.y; ++k) held |= 1u << (f2i(S.spheres[2 * k + 1].w) & 31);
+        if (held & cs.may) return (held & cs.sure) ? CONE_BLOCKED : CONE_TRACE;
+    }
+    return CONE_TRACE;                                                   // (not reached: every primitive sits in a leaf)
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1190,7 +1291,7 @@ DEVI bool cone_may_hit(const DevScene& sc, bool mb, float time, V3 p, V3 lc, flo
 // MODE: 0 = hard shadows, 1 = soft shadows in the reference's arithmetic, 2 = soft shadows on reciprocals (separate
 // kernels: each needs fewer registers than one kernel holding both searches, which decides how many wavefronts fit)
 template <int SUB, bool LDSP, int MODE>
-__global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAVES) void k_shadow(DevScene sc_arg, DevFrame f, DevWork w, int lv_begin, int lv_end) {
+__global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAVES) void k_shadow(DevScene sc_arg, DevFrame f, DevWork w, int lv_begin, int lv_end, int phase, int sq_k) {
     extern __shared__ float4 s_mem[];
     DevScene sc = sc_arg;
     float4* s_nodes = s_mem;
@@ -1214,9 +1315,15 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     // grouped: the SS sample rays of a (hit, light) pair sit side by side inside one wavefront and are counted with a
     // ballot.  The launch's items are then the PAIRS (see the two phases below), otherwise the rays.
     const bool grouped = (SS <= 64) && ((SS & (SS - 1)) == 0);
+    const int ss_shift = 31 - __clz(SS);
+    const int pairs_per_pass = RT_BLOCK >> ss_shift;
+    // phase: 0 = the launch classifies its pairs and traces what needs tracing; 1 = it classifies and hands the pairs to
+    // trace to queue sq_k in memory; 2 = it traces that queue (segments = the queue's regions, chunks = pairs_per_pass
+    // pairs: every workgroup pass is full whatever part of the image the pairs came from).
     const unsigned per = grouped ? (unsigned)L : (unsigned)(L * SS);    // the host keeps a segment's rays below 2^31
-    const int n_seg = (lv_end - lv_begin + 1) * w.regions;
+    const int n_seg = phase == 2 ? w.regions : (lv_end - lv_begin + 1) * w.regions;
     for (int sg = threadIdx.x; sg < n_seg; sg += blockDim.x) {
+        if (phase == 2) { s_items[sg] = (unsigned)min(w.ctr[RT_CTR_SHADOWQ(sq_k, sg)], w.sq_rcap); continue; }
         const int lv = lv_begin + sg / w.regions, rg = sg % w.regions;
         s_items[sg] = (unsigned)min(w.ctr[RT_CTR_NODE(lv, rg)], w.node_rcap[lv]) * (unsigned)w.slot_mul[lv] * per;
         s_nbase[sg] = w.node_off[lv] + rg * w.node_rcap[lv];
@@ -1225,8 +1332,9 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        const unsigned per_chunk = phase == 2 ? (unsigned)pairs_per_pass : (unsigned)RT_BLOCK;
         int acc = 0;
-        for (int sg = 0; sg < n_seg; ++sg) { s_pre[sg] = acc; acc += (int)((s_items[sg] + RT_BLOCK - 1) / RT_BLOCK); }
+        for (int sg = 0; sg < n_seg; ++sg) { s_pre[sg] = acc; acc += (int)((s_items[sg] + per_chunk - 1) / per_chunk); }
         s_pre[n_seg] = acc;
     }
     __syncthreads();
@@ -1235,7 +1343,6 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     if (f.use_bvh) stage_bvh(sc, s_nodes, (int4*)(s_mem + 2 * sc.n_nodes), !SUB);
     if (LDSP) stage_prims(sc, s_mem + 2 * sc.n_nodes + 2 * sc.n_leaves);
 
-    const int ss_shift = 31 - __clz(SS);
     // the cone test loops over every primitive: for scenes with a handful of them
     const bool cull = f.cull_cones && sc.fileset.n_planes + sc.fileset.n_cubes + sc.fileset.n_spheres <= 8;
     int* __restrict__ out = (int*)w.shadow;
@@ -1286,10 +1393,34 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     };
 
     int seg = 0;
+    if (grouped && phase == 2) {
+        // the queued pairs, pairs_per_pass at a time: SS neighbouring lanes per pair, counted with a ballot
+        for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
+            while (seg < n_seg - 1 && g >= __builtin_amdgcn_readfirstlane(s_pre[seg + 1])) ++seg;
+            const int k = (g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * pairs_per_pass + (int)(threadIdx.x >> ss_shift), j = (int)(threadIdx.x & (unsigned)(SS - 1));
+            const bool active = k < __builtin_amdgcn_readfirstlane((int)s_items[seg]);
+            bool unblocked = false; int it = 0;
+            if (active) {
+                const int4 e = w.sq[(size_t)(sq_k * w.regions + seg) * (size_t)w.sq_rcap + (size_t)k];
+                it = e.x;
+                const int l = (L == 1) ? 0 : it % L;
+                ++n_rays;
+                unblocked = sample_unblocked(e.y, e.z, l, j, w.n_a[e.y], (L == 1) ? light0 : sc.lights[l]);
+            }
+            const unsigned long long m = __ballot(active && unblocked);
+            if (active && j == 0) {
+                const int lane0 = __lane_id();
+                out[it] = __popcll((SS == 64) ? m : ((m >> lane0) & ((1ull << SS) - 1ull)));
+            }
+        }
+        if (f.count_stats) block_stat_add(&w.stats[RT_S_SHADOW], n_rays, s_tmp);
+        return;
+    }
     if (grouped) {
         // Two phases per round.  (1) One lane per (hit, light) PAIR of a chunk of RT_BLOCK pairs decides what the pair
-        // needs: nothing when the surface faces away from the light (count 0) or when no sample ray can reach any
-        // primitive (count SS, see cone_may_hit), otherwise its SS sample rays, and then queues the pair in LDS.  (2) Queued
+        // needs: nothing when the surface faces away from the light (count 0), when no sample ray can reach any primitive
+        // (count SS) or when every sample ray is certain to be blocked (count 0; see cone_sets), otherwise its SS
+        // sample rays, and then queues the pair in LDS.  (2) Queued
         // pairs are expanded to rays, RT_BLOCK at a time, SS neighbouring lanes per pair, and counted with a ballot.
         // The per-pair work is so done once, not once per sample, and every wavefront that traces is full of rays that
         // need tracing (the workgroup's last one aside).
@@ -1299,10 +1430,10 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         __shared__ unsigned short s_qcp[QCAP];                        // ... and which of the node's copies (< 4096)
         __shared__ int s_qn, s_next;
         __shared__ unsigned s_qcnt[SUB ? QCAP / 2 : 1];              // the drain's unblocked samples per queued pair, 16 bits each
+        __shared__ int s_gbase, s_gfit;
         if (threadIdx.x == 0) { s_qn = 0; s_next = 0; }
         if (SUB) for (int k = threadIdx.x; k < QCAP / 2; k += blockDim.x) s_qcnt[k] = 0u;
         __syncthreads();
-        const int pairs_per_pass = RT_BLOCK >> ss_shift;
         for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
             while (seg < n_seg - 1 && g >= __builtin_amdgcn_readfirstlane(s_pre[seg + 1])) ++seg;
             const unsigned i = (unsigned)(g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * RT_BLOCK + threadIdx.x;   // pair of the segment
@@ -1324,9 +1455,15 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                 if (cp == 0 || f2i(b.w) < 0) {
                     const float4 lt = (L == 1) ? light0 : sc.lights[l];
                     if (!faces_light(a, b, lt)) out[item] = 0;
-                    else if (!SUB && MODE != 0 && cull &&
-                             !cone_may_hit(sc, f.motion_blur != 0, a.w, mk(a.x, a.y, a.z), mk(lt.x, lt.y, lt.z), f.light_radius,
-                                           f.cull_own ? (f2i(b.w) & 0x7fffffff) : -1, mk(b.x, b.y, b.z))) out[item] = SS;
+                    else if (!SUB && MODE != 0 && cull) {
+                        const ConeSets cs = cone_sets(sc, f.motion_blur != 0, a.w, mk(a.x, a.y, a.z), mk(lt.x, lt.y, lt.z), f.light_radius,
+                                                      f.cull_own ? (f2i(b.w) & 0x7fffffff) : -1, mk(b.x, b.y, b.z), f.cull_umbra != 0);
+                        const int what = cone_outcome(sc, s_nodes, s_leaves, f.use_bvh != 0, cs);
+                        if (what == CONE_TRACE) queue = true; else out[item] = what == CONE_NONE ? SS : 0;
+#ifdef RT_SHADOW_HIST
+                        qcp |= (int)(cs.may & 7u) << 12;
+#endif
+                    }
                     else queue = true;
                 }
             }
@@ -1502,14 +1639,42 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                 __syncthreads();
                 continue;
             }
-            while (qn >= pairs_per_pass || (last && qn > 0)) {           // after the last chunk the queue is emptied
+            // (phase 1 traces nothing itself unless the queue in memory is full)
+            bool trace_here = phase != 1, empty_it = last;
+            if (!SUB && phase == 1 && (qn > QCAP - RT_BLOCK || (last && qn > 0))) {
+                // The queue goes to memory: one atomic per workgroup and queue-full (the regions spread those over several
+                // counters), the entries behind it.  What a full region cannot take stays here and is traced below.
+                if (threadIdx.x == 0) {
+                    const int rg = (int)(blockIdx.x % (unsigned)w.regions);
+                    const int at = atomicAdd(&w.ctr[RT_CTR_SHADOWQ(sq_k, rg)], qn);
+                    s_gfit = max(0, min(qn, w.sq_rcap - at));
+                    s_gbase = (sq_k * w.regions + rg) * w.sq_rcap + at;
+                }
+                __syncthreads();
+                const int fit = s_gfit;
+                int4* __restrict__ dst = w.sq + (size_t)s_gbase;
+                for (int k = threadIdx.x; k < fit; k += blockDim.x) dst[k] = make_int4(s_q[k], s_qnode[k], (int)s_qcp[k], 0);
+                if (fit < qn) {
+                    // (the rest moves to the front of the queue)
+                    int mq[QCAP / RT_BLOCK], mn[QCAP / RT_BLOCK]; unsigned short mc[QCAP / RT_BLOCK];
+#pragma unroll
+                    for (int u = 0; u < QCAP / RT_BLOCK; ++u) { const int k = fit + u * RT_BLOCK + (int)threadIdx.x; if (k < qn) { mq[u] = s_q[k]; mn[u] = s_qnode[k]; mc[u] = s_qcp[k]; } }
+                    __syncthreads();
+#pragma unroll
+                    for (int u = 0; u < QCAP / RT_BLOCK; ++u) { const int k = u * RT_BLOCK + (int)threadIdx.x; if (fit + k < qn) { s_q[k] = mq[u]; s_qnode[k] = mn[u]; s_qcp[k] = mc[u]; } }
+                }
+                __syncthreads();
+                qn -= fit;
+                trace_here = empty_it = qn > 0;
+            }
+            while (trace_here && (qn >= pairs_per_pass || (empty_it && qn > 0))) {     // after the last chunk the queue is emptied
                 const int take = min(qn, pairs_per_pass), first = qn - take;
                 const int k = (int)(threadIdx.x >> ss_shift), j = (int)(threadIdx.x & (unsigned)(SS - 1));
                 const bool active = k < take;
                 bool unblocked = false; int it = 0;
                 if (active) {
                     it = s_q[first + k];
-                    const int node = s_qnode[first + k], cp = (int)s_qcp[first + k];
+                    const int node = s_qnode[first + k], cp = (int)s_qcp[first + k] & 0xfff;
                     const int l = (L == 1) ? 0 : it % L;
                     ++n_rays;
                     unblocked = sample_unblocked(node, cp, l, j, w.n_a[node], (L == 1) ? light0 : sc.lights[l]);
@@ -1519,6 +1684,12 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                     const int lane0 = __lane_id();
                     const unsigned long long grp = (SS == 64) ? m : ((m >> lane0) & ((1ull << SS) - 1ull));
                     out[it] = __popcll(grp);
+#ifdef RT_SHADOW_HIST
+                    // development: how many traced pairs end fully blocked / partly / fully unblocked (level 0; deeper levels)
+                    { const int cnt = __popcll(grp); atomicAdd(&w.stats[RT_S_WALK + (lv_begin ? 20 : 16) + (cnt == 0 ? 0 : cnt == SS ? 2 : 1)], 1ull);
+                      const int may3 = (int)s_qcp[first + k] >> 12;
+                      if (cnt == SS) atomicAdd(&w.stats[RT_S_WALK + may3], 1ull); else if (cnt == 0) atomicAdd(&w.stats[RT_S_WALK + 8 + may3], 1ull); else atomicAdd(&w.stats[RT_S_WALK + 24 + may3], 1ull); }
+#endif
                 }
                 qn = first;
             }
@@ -1927,9 +2098,9 @@ void rt_launch_extend_part2(hipStream_t s, const DevScene& sc, const DevFrame& f
 void rt_launch_fused_part0(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid, size_t lds, bool ldsp);
 void rt_launch_fused_part1(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid, size_t lds, bool ldsp);
 void rt_launch_fused_part2(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid, size_t lds, bool ldsp);
-void rt_launch_shadow_part0(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, size_t lds, bool ldsp, int mode);
-void rt_launch_shadow_part1(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, size_t lds, bool ldsp, int mode);
-void rt_launch_shadow_part2(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, size_t lds, bool ldsp, int mode);
+void rt_launch_shadow_part0(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, size_t lds, bool ldsp, int mode, int phase, int sq_k);
+void rt_launch_shadow_part1(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, size_t lds, bool ldsp, int mode, int phase, int sq_k);
+void rt_launch_shadow_part2(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, size_t lds, bool ldsp, int mode, int phase, int sq_k);
 
 #if RT_PART_KIND == 1
 void RT_CAT(rt_launch_extend_part, RT_PART_SUB)(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid, size_t lds, bool ldsp) {
@@ -1961,12 +2132,12 @@ void RT_CAT(rt_launch_fused_part, RT_PART_SUB)(hipStream_t s, const DevScene& sc
 #endif
 
 #if RT_PART_KIND == 3
-void RT_CAT(rt_launch_shadow_part, RT_PART_SUB)(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, size_t lds, bool ldsp, int mode) {
+void RT_CAT(rt_launch_shadow_part, RT_PART_SUB)(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, size_t lds, bool ldsp, int mode, int phase, int sq_k) {
     constexpr int SUB = RT_PART_SUB;
 #define RT_SHADOW_LAUNCH(LDSP) \
-    do { if (mode == 2) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 2>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); \
-         else if (mode == 1) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 1>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); \
-         else hipLaunchKernelGGL((k_shadow<SUB, LDSP, 0>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end); } while (0)
+    do { if (mode == 2) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 2>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end, phase, sq_k); \
+         else if (mode == 1) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 1>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end, phase, sq_k); \
+         else hipLaunchKernelGGL((k_shadow<SUB, LDSP, 0>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end, phase, sq_k); } while (0)
     if (SUB == 0 && ldsp) RT_SHADOW_LAUNCH((SUB == 0));
     else RT_SHADOW_LAUNCH(false);
 #undef RT_SHADOW_LAUNCH
@@ -1981,8 +2152,8 @@ __global__ void k_begin_frame(uint4* __restrict__ zero, size_t n_words, int tail
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) zero[i] = make_uint4(0u, 0u, 0u, 0u);
     if (blockIdx.x == 0) {
         if ((int)threadIdx.x < tail_bytes) ((unsigned char*)(zero + n_words))[threadIdx.x] = 0;      // < 16 bytes past the last word
-        for (int i = threadIdx.x; i < RT_REGIONS * 2 * RT_MAX_LEVELS; i += blockDim.x)          // the words in use
-            ctr[(i / (2 * RT_MAX_LEVELS)) * RT_CTR_REGION_INTS + i % (2 * RT_MAX_LEVELS)] = 0;
+        for (int i = threadIdx.x; i < RT_REGIONS * RT_CTR_WORDS_IN_USE; i += blockDim.x)        // the words in use
+            ctr[(i / RT_CTR_WORDS_IN_USE) * RT_CTR_REGION_INTS + i % RT_CTR_WORDS_IN_USE] = 0;
         if (stats) for (int i = threadIdx.x; i < RT_S_TOTAL; i += blockDim.x) stats[i] = 0ull;
     }
 }
@@ -2021,14 +2192,20 @@ void rt_launch_primary_shaded(hipStream_t s, const DevScene& sc, const DevFrame&
     else rt_launch_fused_part0(s, sc, f, w, grid, lds, ldsp);
 }
 
-void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid) {
+void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, int grid_drain) {
     const size_t lds = bvh_lds_bytes(sc, f, !f.use_bvh);
     const int mode = !f.soft_shadows ? 0 : (f.fast_samples ? 2 : 1);  // hard shadows are deterministic: always exact
     const int sub = scene_sub(sc);
     const bool ldsp = !sub && sc.lds_prims != 0;
-    if (sub == 2) rt_launch_shadow_part2(s, sc, f, w, lv_begin, lv_end, grid, lds, false, mode);
-    else if (sub == 1) rt_launch_shadow_part1(s, sc, f, w, lv_begin, lv_end, grid, lds, false, mode);
-    else rt_launch_shadow_part0(s, sc, f, w, lv_begin, lv_end, grid, lds, ldsp, mode);
+    if (sub == 2) rt_launch_shadow_part2(s, sc, f, w, lv_begin, lv_end, grid, lds, false, mode, 0, 0);
+    else if (sub == 1) rt_launch_shadow_part1(s, sc, f, w, lv_begin, lv_end, grid, lds, false, mode, 0, 0);
+    else if (w.sq && mode != 0) {
+        // (the context provides the queue where it pays: soft shadows of tiny scenes with the cone rules on, sample counts
+        // that tile a wavefront).  Launches of one batch may run side by side: each has a queue of its own.
+        const int sq_k = lv_begin < RT_SHADOWQ_LAUNCHES - 1 ? lv_begin : RT_SHADOWQ_LAUNCHES - 1;
+        rt_launch_shadow_part0(s, sc, f, w, lv_begin, lv_end, grid, lds, ldsp, mode, 1, sq_k);
+        rt_launch_shadow_part0(s, sc, f, w, lv_begin, lv_end, grid_drain, lds, ldsp, mode, 2, sq_k);
+    } else rt_launch_shadow_part0(s, sc, f, w, lv_begin, lv_end, grid, lds, ldsp, mode, 0, 0);
 }
 
 void rt_launch_sort_keys(hipStream_t s, const DevScene& sc, const DevWork& w, int level, unsigned* keys, unsigned* slots) {

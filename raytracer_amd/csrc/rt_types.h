@@ -101,6 +101,7 @@ struct DevFrame {
     int replicate;                 // soft shadows: the first reflection of a path is traced gr_samples times (see k_extend)
     int cull_cones;                // soft shadows of tiny scenes: (hit, light) pairs whose whole cone of sample rays misses everything are not traced
     int cull_own;                  // ... and a convex primitive (sphere, cube) is not searched for the sample rays that leave its own surface outwards
+    int cull_umbra;                // ... and pairs whose every sample ray is certain to be blocked by one convex primitive (count 0) are not traced either
     int bundle;                    // ... as ONE traced ray whose node has gr_samples copies (replicate, no glossy perturbation)
     int count_stats;               // kernels add their ray counts to DevWork::stats (one atomic per workgroup and counter)
     // sharding
@@ -151,6 +152,11 @@ struct DevWork {
     int node_rcap[RT_MAX_LEVELS];  // [level] nodes one region of the level can hold
     int link_rcap[RT_MAX_LEVELS];  // [level] rays one region of the level's queue can hold (level >= 1)
     int regions;                   // regions in use: 1, 2, 4 or RT_REGIONS (small batches do not need the spread)
+    // Soft shadows of tiny scenes: (hit, light) pairs whose sample rays must be traced, queued by the launch that
+    // classifies the pairs and traced by a second launch that deals them out evenly (see k_shadow).  One queue per
+    // shadow launch of a batch (RT_SHADOWQ_LAUNCHES), each cut into `regions` parts of sq_rcap entries with their own
+    // counters: entry = (index into shadow[], node, copy, 0).  NULL / 0: pairs are traced by the workgroup that met them.
+    int4* sq; int sq_rcap;
 };
 
 // ctr[] slots: allocation counters per (level, region), zeroed at the start of every batch.  Each recursion level owns
@@ -167,6 +173,9 @@ struct DevWork {
 #define RT_CTR_REGION_INTS 4096
 #define RT_CTR_NODE(level, region) ((region) * RT_CTR_REGION_INTS + 2 * (level))          // hits recorded at `level`
 #define RT_CTR_LINK(level, region) ((region) * RT_CTR_REGION_INTS + 2 * (level) - 1)      // rays queued for `level` (>= 1)
+#define RT_SHADOWQ_LAUNCHES 3
+#define RT_CTR_SHADOWQ(k, region) ((region) * RT_CTR_REGION_INTS + 2 * RT_MAX_LEVELS + (k))  // pairs queued by shadow launch k of the batch
+#define RT_CTR_WORDS_IN_USE (2 * RT_MAX_LEVELS + RT_SHADOWQ_LAUNCHES)
 enum { RT_C_TOTAL = RT_REGIONS * RT_CTR_REGION_INTS };
 // stats[] slots
 // *_REF = what the reference would trace: without glossy perturbation it re-traces gr_samples identical reflection
@@ -191,7 +200,7 @@ static inline int rt_sub_stack_entries(int depth) { return 3 * ((depth + 1) / 2)
 // kernel launchers (rt_kernels.hip)
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);
 void rt_launch_primary_shaded(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid);
-void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid);
+void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, int grid_drain);
 void rt_launch_sort_keys(hipStream_t s, const DevScene& sc, const DevWork& w, int level, unsigned* keys, unsigned* slots);
 void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);
 void rt_launch_begin_frame(hipStream_t s, const DevWork& w, void* zero, size_t zero_bytes, bool zero_stats);

@@ -329,3 +329,51 @@ def test_untraced_soft_shadow_cones_with_polygons_that_are_not_planar(textures_d
             assert got[0][0].max() > 0
             assert np.array_equal(got[0][0], got[1][0]), f"case {k} flags {flags}: {(got[0][0] != got[1][0]).any(axis=2).sum()} pixels differ"
             assert got[0][1].shadow_rays < got[1][1].shadow_rays
+
+
+@pytest.mark.parametrize("scene,flags", [("ref", ["-r", "-rd", "4", "-ss", "-sss", "16"]), ("ref", ["-u", "-ss", "-sss", "16", "-r"]), ("ref", ["-ss", "-sss", "64"]),
+                                         ("glass_tex", ["-t", "-rd", "2", "-ss", "-sss", "8"]), ("bvh5", ["-ss", "-sss", "16", "-r"]),
+                                         ("mirror", ["-r", "-rd", "3", "-ss", "-sss", "4"]), ("cube_mb", ["-m", "-mbs", "2", "-ss", "-sss", "16"])])
+def test_pairs_in_full_shadow_and_the_queue_of_pairs_to_trace_change_no_pixel(scene, flags, textures_dir):
+    """Soft shadows of small scenes, two more things that only move work.  (1) A (hit, light) pair whose whole cone of
+    sample rays passes well inside one sphere or cube at rest, clearly before the light, is written as fully blocked
+    without tracing (option cull_umbra; raytracer.cpp:564 blocks a sample whose reported distance is below the light
+    sample's, and bvh.cpp:35-105 returns that primitive's leaf when no earlier leaf can report anything).  (2) The pairs
+    that do need tracing go through a queue in memory to a launch of their own (option shadow_queue); a queue too
+    small for them leaves the rest with the workgroup that met them.  Every combination renders the same frame."""
+    cfg, _ = api.parse_args(flags); cfg.seed = 29
+    ls = api.LoadedScene(cases.SCENES[scene](), cfg, textures_dir)
+    for fast in (1, 0):
+        base = None
+        for opts in ({"cull_umbra": 0, "shadow_queue": 0}, {"cull_umbra": 1, "shadow_queue": 0}, {"cull_umbra": 1, "shadow_queue": 1},
+                     {"cull_umbra": 0, "shadow_queue": 1, "shadow_queue_rcap": 64}, {"cull_umbra": 1, "shadow_queue": 1, "shadow_queue_rcap": 1000, "grid_shadow": 37}):
+            r = api.Renderer(0); r.set_option("fast_samples", fast)
+            for k, v in opts.items():
+                r.set_option(k, v)
+            r.upload(ls, with_bvh=bool(cfg.bvh))
+            img, st = r.render(cfg); r.close()
+            if base is None:
+                base = (img, st); assert img.max() > 0
+                continue
+            assert np.array_equal(img, base[0]), f"{opts} fast_samples {fast}: {(img != base[0]).any(axis=2).sum()} pixels differ"
+            assert (st.shadow_rays_ref, st.reflection_rays, st.nodes_shaded) == (base[1].shadow_rays_ref, base[1].reflection_rays, base[1].nodes_shaded)
+            if opts["cull_umbra"]:
+                assert st.shadow_rays <= base[1].shadow_rays
+            else:
+                assert st.shadow_rays == base[1].shadow_rays
+    ls.close()
+
+
+def test_full_shadow_rule_saves_most_of_the_reference_scene_s_shadow_rays(textures_dir):
+    """scene.json with the quoted flags: of the pairs the cone rule sends to tracing, most end with every sample blocked
+    or every sample unblocked; the rules together leave under a third of them traced, and nothing changes on the film
+    (that is the test above)."""
+    cfg, _ = api.parse_args(["-r", "-rd", "4", "-ss", "-sss", "16"]); cfg.seed = 3
+    ls = api.LoadedScene(cases.reference_scene(640, 360), cfg, textures_dir)
+    traced = {}
+    for umbra in (0, 1):
+        r = api.Renderer(0); r.set_option("cull_umbra", umbra); r.upload(ls, with_bvh=True)
+        _, st = r.render(cfg); r.close()
+        traced[umbra] = st.shadow_rays
+    ls.close()
+    assert traced[1] < 0.6 * traced[0]
