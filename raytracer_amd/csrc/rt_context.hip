@@ -220,6 +220,7 @@ struct rt_ctx {
     bool fuse_simple = true;                 // frames without recursion and with hard shadows: trace, shadow and shade in one kernel
     int shadow_queue_rcap = 0;               // (tests) entries per region of such a queue instead of the planned number
     bool shadow_queue = true;                // ... and the pairs that do need tracing go through a queue in memory to a launch of their own
+    bool trace_masks = false;                // ... and traced sample rays only search what their pair's cone can reach
     bool cull_umbra = true;                  // ... and pairs whose whole cone of sample rays is certain to be blocked
     bool cull_own = true;                    // ... where a sphere or cube is left out for the rays that leave its own surface outwards
     bool bundle_reflections = true;          // ... as one traced ray with gr_samples hit records (off: gr_samples traced rays)
@@ -422,6 +423,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "fuse_simple") == 0) { c->fuse_simple = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "shadow_queue_rcap") == 0) { c->shadow_queue_rcap = value > 0 ? (int)std::min<long long>(value, 1 << 24) : 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "shadow_queue") == 0) { c->shadow_queue = value != 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "trace_masks") == 0) { c->trace_masks = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "cull_umbra") == 0) { c->cull_umbra = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "cull_own") == 0) { c->cull_own = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "bundle_reflections") == 0) { c->bundle_reflections = value != 0; c->drop_graphs(); return RT_OK; }
@@ -1250,7 +1252,7 @@ struct WorkPlan {
 static size_t plan_bytes(const WorkPlan& p, bool textures) {
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     return 4 * al(p.cap_rays * 16) + 3 * al(p.cap_nodes * 16) + al(p.cap_slots * 16) + (textures ? al(p.cap_nodes * 8) : 0) + al(p.cap_pix * 4) +
-           al(p.cap_shadow * 4) + al(p.cap_links * 4) + (p.cap_sq ? al(p.cap_sq * 16) : 0);
+           al(p.cap_shadow * 4) + al(p.cap_links * 4) + (p.cap_sq ? al(p.cap_sq * 32) : 0);
 }
 
 static int make_plan(rt_ctx* c, const rt_config* cfg, int D, int L, bool textures, long long n_slots, unsigned long long budget, WorkPlan& p) {
@@ -1277,7 +1279,7 @@ static int make_plan(rt_ctx* c, const rt_config* cfg, int D, int L, bool texture
     const double links_per = nodes_per - 1.0;
     p.grouped = !cfg->soft_shadows || (cfg->ss_samples <= 64 && (cfg->ss_samples & (cfg->ss_samples - 1)) == 0);
     p.shadow_queue = cfg->soft_shadows && p.grouped && L > 0 && c->shadow_queue && c->cull_cones && !c->scene.sub_nodes && c->np + c->nc + c->ns <= 8;
-    const double bytes_per = nodes_per * (16.0 * 3 + (textures ? 8 : 0)) + slots_per * (16.0 + (p.shadow_queue ? 10.0 : 4.0) * std::max(L, 1)) + 4.0 + links_per * 4.0 +
+    const double bytes_per = nodes_per * (16.0 * 3 + (textures ? 8 : 0)) + slots_per * (16.0 + (p.shadow_queue ? 16.0 : 4.0) * std::max(L, 1)) + 4.0 + links_per * 4.0 +
                              (p.fanout ? 2.0 * widest * 32.0 : 0.0);
     // (1/64 of the budget covers the rounding of the regions' capacities, see below)
     long long B = (long long)((double)budget * (63.0 / 64.0) / bytes_per);
@@ -1400,7 +1402,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     int fb = cfg->fallback; if (fb == 0) fb = 1;
     f.fallback_full = (fb == 1);
     f.light_radius = cfg->light_radius; f.seed = cfg->seed; f.fast_samples = c->fast_samples ? 1 : 0; f.count_stats = count_stats ? 1 : 0; f.skip_unlit = c->skip_unlit ? 1 : 0;
-    f.cull_cones = c->cull_cones ? 1 : 0; f.cull_own = c->cull_own ? 1 : 0; f.cull_umbra = c->cull_umbra ? 1 : 0;
+    f.cull_cones = c->cull_cones ? 1 : 0; f.cull_own = c->cull_own ? 1 : 0; f.cull_umbra = c->cull_umbra ? 1 : 0; f.trace_masks = c->trace_masks ? 1 : 0;
     f.replicate = (cfg->soft_shadows && c->replicate_reflections) ? 1 : 0;
     // identical reflection rays are traced once and recorded gr_samples times (the packed hit record holds 12-bit copy numbers)
     f.bundle = (f.replicate && !cfg->glossy_reflect && cfg->gr_samples <= 4096 && c->bundle_reflections) ? 1 : 0;
@@ -1473,7 +1475,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         w.n_pix = (int*)take(cap_pix * 4);
         w.shadow = (float*)take(plan.cap_shadow * 4);
         w.link = (int*)take(cap_links * 4);
-        if (plan.cap_sq) w.sq = (int4*)take(plan.cap_sq * 16);
+        if (plan.cap_sq) w.sq = (int4*)take(plan.cap_sq * 32);
         if ((size_t)(q - arena) > RT_NOALLOC_BYTES) {
             if (took) release_scratch(c);
             return c->fail(RT_ERR_CAPACITY, "rt_render_device_noalloc: work plan exceeds the scratch array");
@@ -1481,7 +1483,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     } else {
         const bool grow = cap_nodes > c->n_a.n || plan.cap_slots > c->n_col.n || cap_links > c->link.n || cap_rays > c->q_a[0].n || (size_t)n_slots > c->accum.n ||
                           (f.textures && cap_nodes > c->n_uv.n) || plan.cap_shadow > c->shadow.n || cap_pix > c->n_pix.n ||
-                          (sorting && (cap_rays > c->sort_keys[0].n || sort_temp_bytes > c->sort_temp.n)) || plan.cap_sq > c->sq.n;
+                          (sorting && (cap_rays > c->sort_keys[0].n || sort_temp_bytes > c->sort_temp.n)) || 2 * plan.cap_sq > c->sq.n;
         if (grow) {
             // Recorded frames hold the addresses of the buffers that are about to be freed: drop every recording before any
             // reallocation, and wait for the frames still in flight on either stream.
@@ -1497,7 +1499,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
         RT_HIP(c, c->n_pix.resize(cap_pix));
         RT_HIP(c, c->shadow.resize(plan.cap_shadow));
         RT_HIP(c, c->link.resize(cap_links));
-        if (plan.cap_sq) RT_HIP(c, c->sq.resize(plan.cap_sq));
+        if (plan.cap_sq) RT_HIP(c, c->sq.resize(2 * plan.cap_sq));
         if (sorting) {
             for (int q = 0; q < 2; ++q) { RT_HIP(c, c->sort_keys[q].resize(cap_rays)); RT_HIP(c, c->sort_slots[q].resize(cap_rays)); }
             RT_HIP(c, c->sort_temp.resize(sort_temp_bytes));

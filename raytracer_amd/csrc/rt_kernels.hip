@@ -1063,6 +1063,71 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
     }
 }
 
+// Sample rays of a pair whose cone can only reach the primitives in `may` (bits by global id, see cone_sets): the same
+// search as trace<false, 0, FAST> with stop_below = the light sample's distance, leaving out what cannot be hit -
+// primitives outside `may`, and whole subtrees of the first level that hold none of them (sub_held[i]: the primitives in
+// the leaves under node i).  A primitive that cannot be hit reports nothing, so the leaf that ends the reference's walk,
+// and whether its closest distance is below stop_below, are the same.  Returns that decision: blocked.
+template <bool FAST>
+DEVI bool test_prims_of(const DevPrimSet& S, const Ray& r, bool mb, int p0, int pn, int c0, int cn, int s0, int sn, bool leaf_rule, float stop_below, unsigned may, bool& any) {
+    float closest = leaf_rule ? INFINITY : FLT_MAX;
+    for (int i = p0; i < p0 + pn; ++i) {
+        float t;
+        if (!((may >> (f2i(S.planes[3 * i + 2].x) & 31)) & 1u)) continue;
+        if (plane_test<false, FAST>(S.planes + 3 * i, S.edges, nullptr, r, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
+            any = true; closest = t;
+            if (t < stop_below) return true;
+        }
+    }
+    for (int i = c0; i < c0 + cn; ++i) {
+        float t;
+        if (!((may >> (f2i(S.cubes[6 * i + 3].z) & 31)) & 1u)) continue;
+        if (cube_test<false, FAST>(S.cubes + 6 * i, r, mb, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
+            any = true; closest = t;
+            if (t < stop_below) return true;
+        }
+    }
+    for (int i = s0; i < s0 + sn; ++i) {
+        float t;
+        if (!((may >> (f2i(S.spheres[2 * i + 1].w) & 31)) & 1u)) continue;
+        if (sphere_test<false, FAST>(S.spheres + 2 * i, r, mb, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
+            any = true; closest = t;
+            if (t < stop_below) return true;
+        }
+    }
+    return false;
+}
+
+template <bool FAST>
+DEVI bool blocked_among(const DevScene& sc, const DevFrame& f, const float4* __restrict__ nodes, const int4* __restrict__ leaves, const unsigned* __restrict__ sub_held,
+                        const Ray& r, float stop_below, unsigned may) {
+    const bool mb = f.motion_blur != 0;
+    bool any = false;
+    if (!f.use_bvh) {
+        const DevPrimSet& FS = sc.fileset;
+        return test_prims_of<FAST>(FS, r, mb, 0, FS.n_planes, 0, FS.n_cubes, 0, FS.n_spheres, false, stop_below, may, any);
+    }
+    const float ax = fabsf(r.d.x), ay = fabsf(r.d.y), az = fabsf(r.d.z);
+    const bool fast_ok = ax > 1e-18f && ax < 1e18f && ay > 1e-18f && ay < 1e18f && az > 1e-18f && az < 1e18f;
+    const V3 rcp = mk(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
+    int i = 0;
+    const int n = sc.n_nodes;
+    while (i < n) {
+        const float4 a = nodes[2 * i];
+        if (!(sub_held[i] & may)) { i = f2i(a.w); continue; }
+        const float4 b = nodes[2 * i + 1];
+        if (!slab<FAST>(r, a, b, rcp, fast_ok)) { i = f2i(a.w); continue; }
+        const int leaf = f2i(b.w);
+        ++i;
+        if (leaf >= 0) {
+            const int4 l0 = leaves[2 * leaf], l1 = leaves[2 * leaf + 1];
+            if (test_prims_of<FAST>(sc.leafset, r, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, true, stop_below, may, any)) return true;
+            if (any) return false;                                       // this leaf's result is what the reference returns
+        }
+    }
+    return false;
+}
+
 // Soft shadows of a scene with a handful of primitives: what the sample rays of a (hit, light) pair can hit, decided
 // once per pair.  The sample rays lie on lines through the hit point p (they start 0.001 along their own direction,
 // raytracer.cpp:549) and aim at points of the ball of radius R around the light (raytracer.cpp:541), so their
@@ -1113,76 +1178,72 @@ DEVI bool cone_surely_hits_sphere(V3 p, V3 a, float sin_t, float cos_t, V3 c, fl
 //   neighbouring face at an edge), so the far slab distance is -e / N.d - 0.001 / scale <= 1e-4 as long as
 //   e <= N.d (1e-4 + 0.001 / scale): tmax then never exceeds the test's own threshold of 1e-4 and it reports no hit.
 // Such a primitive is left out of the search below.
-// The same question against a cube itself rather than the sphere around it, in the cube's own frame (cube.cpp:126-168:
+// The same questions against a cube itself rather than the sphere around it, in the cube's own frame (cube.cpp:126-168:
 // translate by the location at the ray's time, rotate back, divide by the scale; the cube is then [-1, 1]^3 and
-// distances are in units of its half edge).  Take a point X of a sample ray and the plane through X at right angles to
-// the axis: it meets the axis at A = p + u a, and X - A is at right angles to a and at most u tan(theta) long, so along
-// the cube's axis i it measures at most u tan(theta) sqrt(1 - al_i^2) (al: the axis in the cube's frame).  If X lies in
-// the cube enlarged by eps (for what the float test may report outside it), then |pl_i + u al_i| <= 1 + eps +
-// u tan(theta) sqrt(1 - al_i^2) for the three axes i: six linear conditions on u >= 0.  No u satisfies them all: no
-// sample ray reaches the cube.
-// (eps: the test treats a direction component below 1e-5 as zero, which moves a reported point by up to 1e-5 of the
-// distance travelled, and its slab distances carry a few 1e-7 of their size in rounding; taken ten times over.)
+// distances are in units of its half edge).  Seen from a point outside it, a cube of half edge h is the convex polygon
+// of its silhouette edges - the edges between a face that looks at the point and one that does not - and a line through
+// the point meets the cube exactly when its direction x lies on the inner side of every plane through the point and a
+// silhouette edge: n_e . x >= 0 with n_e the plane's unit normal turned towards the cube's centre.  For the cone's
+// axis al and half angle theta:
+//   min_e n_e . al < -sin(theta): every direction of the cone lies outside one of the planes - no line of the cone meets the cube;
+//   min_e n_e . al >  sin(theta): every direction lies inside all of them - every line of the cone passes through the cube.
+// An edge along axis k at (s_i h, s_j h) of the other two axes: with d = corner - point, the plane's normal is d x e_k =
+// (d_j, -d_i) on the axes (i, j) (cyclic order), so an edge costs a dozen operations.  Returns that minimum;
+// `degenerate`: the point lies on the line of a silhouette edge, or inside the cube.
+DEVI float cube_silhouette_margin(V3 pl, V3 al, float h, bool& degenerate) {
+    const float pv[3] = { pl.x, pl.y, pl.z }, av[3] = { al.x, al.y, al.z };
+    float mn = INFINITY;
+    degenerate = !(fmaxf(fmaxf(fabsf(pl.x), fabsf(pl.y)), fabsf(pl.z)) > h);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int i = (k + 1) % 3, j = (k + 2) % 3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float si = (e & 1) ? 1.0f : -1.0f, sj = (e & 2) ? 1.0f : -1.0f;
+            const bool fi = si * pv[i] > h, fj = sj * pv[j] > h;      // does the face on either side of the edge look at the point?
+            const float di = si * h - pv[i], dj = sj * h - pv[j];
+            float ni = dj, nj = -di;
+            if (ni * pv[i] + nj * pv[j] > 0.0f) { ni = -ni; nj = -nj; }
+            const float n2 = ni * ni + nj * nj;
+            const float m = (ni * av[i] + nj * av[j]) * __builtin_amdgcn_rsqf(n2);
+            if (fi != fj) { mn = fminf(mn, m); degenerate = degenerate || !(n2 > 1e-12f) || !(m == m); }
+        }
+    }
+    return mn;
+}
+
+// (eps: the float test treats a direction component below 1e-5 as zero, which moves a reported point by up to 1e-5 of
+// the distance travelled, and its slab distances carry a few 1e-7 of their size in rounding; taken ten times over.)
 DEVI bool cone_may_hit_cube(const float4* __restrict__ rec, bool mb, float time, V3 p, V3 a, float sin_t, float cos_t) {
     const float4 w0 = rec[0], w1 = rec[1], w4 = rec[4], w5 = rec[5];
     V3 loc = mk(w0.x, w0.y, w0.z);
     if (mb) loc = mk(lerp_ref(w0.x, w1.x, time), lerp_ref(w0.y, w1.y, time), lerp_ref(w0.z, w1.z, time));
     const float inv = fabsf(w1.w);                                       // 1 / scale
-    if (!(inv > 1e-6f && inv < 1e6f) || !(cos_t > 0.1f)) return true;
+    if (!(inv > 1e-6f && inv < 1e6f)) return true;
     const V3 pl = rot_inv(p - loc, w4, w5) * inv, al = rot_inv(a, w4, w5);
     const float dist = __builtin_amdgcn_sqrtf(dot(pl, pl));
-    const float eps = 2e-3f + 1e-4f * (dist + 1.0f) + 0.002f * inv;      // (the last term: the rays start 0.001 world units beyond p)
-    const float tan_t = sin_t * __builtin_amdgcn_rcpf(cos_t) * 1.002f;
-    const float H = (1.0f + eps) * 1.001f;
-    float lo = 0.0f, hi = (dist + 1.7321f * (1.0f + eps)) * 1.01f;       // no point of the cube is farther from p
-    const float pv[3] = { pl.x, pl.y, pl.z }, av[3] = { al.x, al.y, al.z };
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float k = tan_t * __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - av[i] * av[i])) + 1e-5f;
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg) {
-            // c u <= b
-            const float c = (sg ? -av[i] : av[i]) - k, b = H - (sg ? -pv[i] : pv[i]);
-            if (c > 1e-6f) hi = fminf(hi, b * __builtin_amdgcn_rcpf(c) * (b > 0.0f ? 1.0001f : 0.9999f));
-            else if (c < -1e-6f) lo = fmaxf(lo, b * __builtin_amdgcn_rcpf(c) * (b > 0.0f ? 1.0001f : 0.9999f));
-            else if (b < -1e-3f * (1.0f + hi)) return false;             // |c| tiny: the condition hardly depends on u
-        }
-    }
+    const float eps = 2e-3f + 1e-4f * (dist + 1.0f);
+    bool degenerate;
+    const float mn = cube_silhouette_margin(pl, al, (1.0f + eps) * 1.001f, degenerate);
     // (a NaN anywhere makes the comparison false: "may hit")
-    return !(lo > hi + 1e-4f);
+    return degenerate || !(mn < -(sin_t * 1.002f + 1e-4f));
 }
 
-// A cube at rest, in its own frame.  The plane at right angles to the axis at depth u meets every line of the cone
-// within u tan(theta) of the axis point, i.e. within u tan(theta) sqrt(1 - al_i^2) along the cube's axis i.  If for some
-// u that whole disc lies in the cube shrunk to 0.97 - |pl_i + u al_i| + u tan(theta) sqrt(1 - al_i^2) <= 0.97 for the
-// three axes, again six linear conditions - every sample ray passes through a point well inside the cube, so
-// cube.cpp:170-215 finds tmin < tmax.  With p outside the slab of some axis by more than 0.02 half edges the ray needs
-// at least 0.02 of local distance to get in, so tmin > 1e-4 and is what the test reports: at most the distance to that
-// inner point, u / cos(theta) (the direction component on that axis is then far above the 1e-5 below which the test
-// treats the ray as parallel).
+// A cube at rest, shrunk to 0.97: every line of the cone passes through a point well inside the cube, so cube.cpp:170-215
+// finds tmin < tmax.  With p outside the slab of some axis by more than 0.02 half edges the ray needs at least 0.02 of
+// local distance to get in, so tmin > 1e-4 and is what the test reports - at most the distance to the cube's farthest
+// corner (the direction component on that axis is then far above the 1e-5 below which the test treats the ray as parallel).
 DEVI bool cone_surely_hits_cube(const float4* __restrict__ rec, V3 p, V3 a, float sin_t, float cos_t, float reach) {
     const float4 w0 = rec[0], w1 = rec[1], w4 = rec[4], w5 = rec[5];
     const float inv = fabsf(w1.w), scale = fabsf(w0.w);
-    if (!(inv > 1e-3f && inv < 1e3f) || !(cos_t > 0.1f)) return false;
+    if (!(inv > 1e-3f && inv < 1e3f)) return false;
     const V3 pl = rot_inv(p - mk(w0.x, w0.y, w0.z), w4, w5) * inv, al = rot_inv(a, w4, w5);
     if (!(fmaxf(fmaxf(fabsf(pl.x), fabsf(pl.y)), fabsf(pl.z)) > 1.02f + 0.002f * inv)) return false;
-    const float tan_t = sin_t * __builtin_amdgcn_rcpf(cos_t) * 1.002f;
-    float lo = 0.0f, hi = 500.0f;
-    const float pv[3] = { pl.x, pl.y, pl.z }, av[3] = { al.x, al.y, al.z };
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float k = tan_t * __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - av[i] * av[i])) + 1e-5f;
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg) {
-            // c u <= b
-            const float c = (sg ? -av[i] : av[i]) + k, b = 0.97f - (sg ? -pv[i] : pv[i]);
-            if (c > 1e-6f) hi = fminf(hi, b * __builtin_amdgcn_rcpf(c) * (b > 0.0f ? 0.9999f : 1.0001f));
-            else if (c < -1e-6f) lo = fmaxf(lo, b * __builtin_amdgcn_rcpf(c) * (b > 0.0f ? 0.9999f : 1.0001f));
-            else if (!(b > 1e-3f * (1.0f + fabsf(lo)))) return false;
-        }
-    }
-    if (!(lo + 1e-4f < hi)) return false;                                // (NaN: not certain)
-    return (lo + 2e-4f) * __builtin_amdgcn_rcpf(cos_t) * scale * 1.001f + 0.003f < reach;
+    const float dist = __builtin_amdgcn_sqrtf(dot(pl, pl));
+    if (!(dist < 500.0f) || !((dist + 1.7321f) * scale * 1.001f + 0.003f < reach)) return false;
+    bool degenerate;
+    const float mn = cube_silhouette_margin(pl, al, 0.97f, degenerate);
+    return !degenerate && mn > sin_t * 1.01f + 2e-4f;
 }
 
 // Bit g of `may` / `sure`: the primitive with global id g (planes, then cubes, then spheres, each in file order) may
@@ -1325,7 +1386,8 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     for (int sg = threadIdx.x; sg < n_seg; sg += blockDim.x) {
         if (phase == 2) { s_items[sg] = (unsigned)min(w.ctr[RT_CTR_SHADOWQ(sq_k, sg)], w.sq_rcap); continue; }
         const int lv = lv_begin + sg / w.regions, rg = sg % w.regions;
-        s_items[sg] = (unsigned)min(w.ctr[RT_CTR_NODE(lv, rg)], w.node_rcap[lv]) * (unsigned)w.slot_mul[lv] * per;
+        // (phase 1 decides per (node, light): the copies of a node share the answer)
+        s_items[sg] = (unsigned)min(w.ctr[RT_CTR_NODE(lv, rg)], w.node_rcap[lv]) * (phase == 1 ? (unsigned)L : (unsigned)w.slot_mul[lv] * per);
         s_nbase[sg] = w.node_off[lv] + rg * w.node_rcap[lv];
         s_sbase[sg] = w.slot_off[lv] + rg * w.node_rcap[lv] * w.slot_mul[lv];
         s_mul[sg] = w.slot_mul[lv];
@@ -1345,13 +1407,34 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
 
     // the cone test loops over every primitive: for scenes with a handful of them
     const bool cull = f.cull_cones && sc.fileset.n_planes + sc.fileset.n_cubes + sc.fileset.n_spheres <= 8;
+    // ... whose first level is a handful of nodes: which primitives (bits by global id) the leaves under each node hold
+    constexpr int MAX_HELD = 64;
+    __shared__ unsigned s_sub_held[SUB || MODE == 0 ? 1 : MAX_HELD];
+    const bool masks = !SUB && MODE != 0 && cull && f.trace_masks && (!f.use_bvh || sc.n_nodes <= MAX_HELD);
+    if (masks && f.use_bvh) {
+        for (int i = threadIdx.x; i < sc.n_nodes; i += blockDim.x) {
+            unsigned held = 0u;
+            const int end = f2i(s_nodes[2 * i].w);
+            for (int k = i; k < end && k < sc.n_nodes; ++k) {
+                const int leaf = f2i(s_nodes[2 * k + 1].w);
+                if (leaf < 0) continue;
+                const int4 l0 = s_leaves[2 * leaf], l1 = s_leaves[2 * leaf + 1];
+                for (int q = l0.x; q < l0.x + l0.y; ++q) held |= 1u << (f2i(sc.leafset.planes[3 * q + 2].x) & 31);
+                for (int q = l0.z; q < l0.z + l0.w; ++q) held |= 1u << (f2i(sc.leafset.cubes[6 * q + 3].z) & 31);
+                for (int q = l1.x; q < l1.x + l1.y; ++q) held |= 1u << (f2i(sc.leafset.spheres[2 * q + 1].w) & 31);
+            }
+            s_sub_held[i] = held;
+        }
+        __syncthreads();
+    }
     int* __restrict__ out = (int*)w.shadow;
     unsigned long long n_rays = 0;
     const float4 light0 = sc.lights[0];                                 // count > 0 implies a light; the usual scene has one
 
     // One sample ray: hard shadows (raytracer.cpp:509-530) or sample j of a soft shadow (raytracer.cpp:534-571).  Returns
     // the distance the reported hit is compared with (the light sample's; -inf for hard shadows: any hit blocks).
-    auto make_sample_ray = [&](int node, int cp, int l, int j, const float4 a, const float4 lt, Ray& sr) __attribute__((always_inline)) -> float {
+    // (path: the hit's path id, n_c[node].z, when the caller has it already; `node` is then not read)
+    auto make_sample_ray = [&](int node, bool have_path, uint32_t path, int cp, int l, int j, const float4 a, const float4 lt, Ray& sr) __attribute__((always_inline)) -> float {
         const V3 p = mk(a.x, a.y, a.z);
         sr.time = a.w;
         if (MODE == 0) {
@@ -1360,7 +1443,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
             sr.o = p + mk(b.x, b.y, b.z) * 1e-2f;                        // raytracer.cpp:515: unflipped geometric normal
             return -INFINITY;
         }
-        uint32_t path = (uint32_t)f2i(w.n_c[node].z);
+        if (!have_path) path = (uint32_t)f2i(w.n_c[node].z);
         if (cp) path = mix32(path + 0x9E3779B1u * (uint32_t)cp);        // every copy of a hit draws its own samples
         const uint3 q = pcg3d(path ^ (f.seed * 0x9E3779B1u), (uint32_t)j, (uint32_t)l * 16u + STREAM_SHADOW);
         const V3 jit = unit_sphere(u01(q.x), u01(q.y), u01(q.z)) * f.light_radius;
@@ -1373,11 +1456,13 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         sr.d = ld;
         return lightDist;
     };
-    auto sample_unblocked = [&](int node, int cp, int l, int j, const float4 a, const float4 lt) __attribute__((always_inline)) -> bool {
+    // may: the pair's cone can only reach these primitives (tiny scenes with the cone rules on), 0 = no such knowledge
+    auto sample_unblocked = [&](int node, bool have_path, uint32_t path, int cp, int l, int j, const float4 a, const float4 lt, unsigned may) __attribute__((always_inline)) -> bool {
         Ray sr;
         Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
-        const float lightDist = make_sample_ray(node, cp, l, j, a, lt, sr);
+        const float lightDist = make_sample_ray(node, have_path, path, cp, l, j, a, lt, sr);
         if (MODE == 0) return !trace<true, SUB>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
+        if (!SUB && MODE != 0 && may != 0u) return !blocked_among<FAST>(sc, f, s_nodes, s_leaves, s_sub_held, sr, lightDist, may);
         // only "closest reported distance < lightDist" is asked for (raytracer.cpp:564)
         const bool hit = trace<false, SUB, FAST>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best, lightDist);
         return !(hit && best.t < lightDist);
@@ -1394,24 +1479,110 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
 
     int seg = 0;
     if (grouped && phase == 2) {
-        // the queued pairs, pairs_per_pass at a time: SS neighbouring lanes per pair, counted with a ballot
-        for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
+        // the queued pairs, pairs_per_pass at a time: SS neighbouring lanes per pair, counted with a ballot.  An entry
+        // holds what a sample ray needs - (index into shadow[], copy | may << 16, path id, hit time), (hit point) - and the
+        // next chunk's entries are requested before this chunk's rays are traced.
+        const int j = (int)(threadIdx.x & (unsigned)(SS - 1));
+        auto fetch = [&](int g, int4& e0, float4& e1) -> bool {
+            if (g >= n_chunks) return false;
             while (seg < n_seg - 1 && g >= __builtin_amdgcn_readfirstlane(s_pre[seg + 1])) ++seg;
-            const int k = (g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * pairs_per_pass + (int)(threadIdx.x >> ss_shift), j = (int)(threadIdx.x & (unsigned)(SS - 1));
-            const bool active = k < __builtin_amdgcn_readfirstlane((int)s_items[seg]);
-            bool unblocked = false; int it = 0;
+            const int k = (g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * pairs_per_pass + (int)(threadIdx.x >> ss_shift);
+            if (k >= __builtin_amdgcn_readfirstlane((int)s_items[seg])) return false;
+            const int4* __restrict__ e = w.sq + 2 * ((size_t)(sq_k * w.regions + seg) * (size_t)w.sq_rcap + (size_t)k);
+            e0 = e[0]; e1 = *(const float4*)(e + 1);
+            return true;
+        };
+        int4 c0 = make_int4(0, 0, 0, 0), n0 = c0; float4 c1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = c1;
+        bool active = fetch((int)blockIdx.x, c0, c1);
+        for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
+            const bool next_active = fetch(g + (int)gridDim.x, n0, n1);
+            bool unblocked = false;
             if (active) {
-                const int4 e = w.sq[(size_t)(sq_k * w.regions + seg) * (size_t)w.sq_rcap + (size_t)k];
-                it = e.x;
-                const int l = (L == 1) ? 0 : it % L;
+                const int l = (L == 1) ? 0 : c0.x % L;
                 ++n_rays;
-                unblocked = sample_unblocked(e.y, e.z, l, j, w.n_a[e.y], (L == 1) ? light0 : sc.lights[l]);
+                unblocked = sample_unblocked(0, true, (uint32_t)c0.z, c0.y & 0xffff, l, j, make_float4(c1.x, c1.y, c1.z, i2f(c0.w)), (L == 1) ? light0 : sc.lights[l], (unsigned)c0.y >> 16);
             }
             const unsigned long long m = __ballot(active && unblocked);
             if (active && j == 0) {
                 const int lane0 = __lane_id();
-                out[it] = __popcll((SS == 64) ? m : ((m >> lane0) & ((1ull << SS) - 1ull)));
+                out[c0.x] = __popcll((SS == 64) ? m : ((m >> lane0) & ((1ull << SS) - 1ull)));
             }
+            active = next_active; c0 = n0; c1 = n1;
+        }
+        if (f.count_stats) block_stat_add(&w.stats[RT_S_SHADOW], n_rays, s_tmp);
+        return;
+    }
+    if (grouped && !SUB && MODE != 0 && phase == 1) {
+        // One lane per (node, light): what its pairs - one per copy of the node, all with the same hit point - need.
+        // Nothing when the surface faces away from the light (count 0), when no sample ray can reach any primitive
+        // (count SS) or when every sample ray is certain to be blocked (count 0; see cone_sets): the counts are written
+        // here.  Otherwise an entry per copy goes to the queue in memory: one atomic per wavefront that queues anything
+        // (the regions spread those over several counters), no workgroup-wide step.  What a full region cannot take is
+        // traced here, lane by lane.
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a, a_next = a, b_next = a;
+        struct NodeAt { bool valid; int item0, node, l, mul; };
+        auto locate = [&](int g, float4& ra, float4& rb) -> NodeAt {
+            NodeAt at; at.valid = false; at.item0 = at.node = at.l = 0; at.mul = 1;
+            if (g >= n_chunks) return at;
+            while (seg < n_seg - 1 && g >= __builtin_amdgcn_readfirstlane(s_pre[seg + 1])) ++seg;
+            const unsigned i = (unsigned)(g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * RT_BLOCK + threadIdx.x;   // (node, light) of the segment
+            if (i >= (unsigned)__builtin_amdgcn_readfirstlane((int)s_items[seg])) return at;
+            int node_local;
+            if (L == 1) { node_local = (int)i; at.l = 0; } else { node_local = (int)(i / (unsigned)L); at.l = (int)(i % (unsigned)L); }
+            at.mul = __builtin_amdgcn_readfirstlane(s_mul[seg]);
+            at.node = __builtin_amdgcn_readfirstlane(s_nbase[seg]) + node_local;
+            at.item0 = (__builtin_amdgcn_readfirstlane(s_sbase[seg]) + node_local * at.mul) * L + at.l;
+            ra = w.n_a[at.node]; rb = w.n_b[at.node];
+            at.valid = true;
+            return at;
+        };
+        const int lane = (int)__lane_id();
+        const int rg = (int)((blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) % (unsigned)w.regions);
+        int4* __restrict__ qbase = w.sq + 2 * (size_t)(sq_k * w.regions + rg) * (size_t)w.sq_rcap;
+        NodeAt cur = locate((int)blockIdx.x, a, b);
+        for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
+            const NodeAt nxt = locate(g + (int)gridDim.x, a_next, b_next);
+            int n_push = 0; unsigned may16 = 0u;
+            // a node of a level with several slots per node has either one copy or all of them (top bit of the id word)
+            const int ncp = (cur.valid && cur.mul > 1 && f2i(b.w) < 0) ? cur.mul : 1;
+            const float4 lt = (L == 1) ? light0 : sc.lights[cur.l];
+            if (cur.valid) {
+                int what = CONE_TRACE;
+                if (!faces_light(a, b, lt)) what = CONE_BLOCKED;
+                else if (cull) {
+                    const ConeSets cs = cone_sets(sc, f.motion_blur != 0, a.w, mk(a.x, a.y, a.z), mk(lt.x, lt.y, lt.z), f.light_radius,
+                                                  f.cull_own ? (f2i(b.w) & 0x7fffffff) : -1, mk(b.x, b.y, b.z), f.cull_umbra != 0);
+                    what = cone_outcome(sc, s_nodes, s_leaves, f.use_bvh != 0, cs);
+                    if (masks) may16 = cs.may & 0xffffu;
+                }
+                if (what == CONE_TRACE) n_push = ncp;
+                else for (int cp = 0; cp < ncp; ++cp) out[cur.item0 + cp * L] = what == CONE_NONE ? SS : 0;
+            }
+            const unsigned long long m1 = __ballot(n_push == 1), mm = __ballot(n_push > 1);
+            if (m1 | mm) {
+                const int mulw = __builtin_amdgcn_readfirstlane(cur.mul);       // (lanes with n_push > 1 push their segment's mul; a wavefront's chunk lies in one segment)
+                const int total = __popcll(m1) + mulw * __popcll(mm);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                int at = 0;
+                const int first_lane = __ffsll((long long)(m1 | mm)) - 1;
+                if (lane == first_lane) at = atomicAdd(&w.ctr[RT_CTR_SHADOWQ(sq_k, rg)], total);
+                at = __shfl(at, first_lane, 64) + __popcll(m1 & below) + mulw * __popcll(mm & below);
+                if (n_push) {
+                    const int path = f2i(w.n_c[cur.node].z);
+                    for (int cp = 0; cp < n_push; ++cp) {
+                        if (at + cp < w.sq_rcap) {
+                            int4* __restrict__ e = qbase + 2 * (size_t)(at + cp);
+                            e[0] = make_int4(cur.item0 + cp * L, cp | (int)(may16 << 16), path, f2i(a.w));
+                            *(float4*)(e + 1) = make_float4(a.x, a.y, a.z, 0.0f);
+                        } else {
+                            int cnt = 0;
+                            for (int j = 0; j < SS; ++j) { ++n_rays; cnt += sample_unblocked(cur.node, true, (uint32_t)path, cp, cur.l, j, a, lt, may16) ? 1 : 0; }
+                            out[cur.item0 + cp * L] = cnt;
+                        }
+                    }
+                }
+            }
+            cur = nxt; a = a_next; b = b_next;
         }
         if (f.count_stats) block_stat_add(&w.stats[RT_S_SHADOW], n_rays, s_tmp);
         return;
@@ -1427,32 +1598,43 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         // (scenes with second-level hierarchies collect more pairs before they trace: see the drain below)
         constexpr int QCAP = 2 * RT_BLOCK;
         __shared__ int s_q[QCAP], s_qnode[QCAP];                      // queued pairs: index into `out`; node
-        __shared__ unsigned short s_qcp[QCAP];                        // ... and which of the node's copies (< 4096)
+        __shared__ unsigned s_qcp[QCAP];                              // ... which of the node's copies (< 4096) | what its sample rays may hit << 16
         __shared__ int s_qn, s_next;
         __shared__ unsigned s_qcnt[SUB ? QCAP / 2 : 1];              // the drain's unblocked samples per queued pair, 16 bits each
-        __shared__ int s_gbase, s_gfit;
         if (threadIdx.x == 0) { s_qn = 0; s_next = 0; }
         if (SUB) for (int k = threadIdx.x; k < QCAP / 2; k += blockDim.x) s_qcnt[k] = 0u;
         __syncthreads();
-        for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
+        // which pair of chunk g this lane decides, and its hit record (requested one chunk ahead of its use)
+        struct PairAt { bool valid; int item, node, cp, l; };
+        auto locate = [&](int g, float4& a, float4& b) -> PairAt {
+            PairAt at; at.valid = false; at.item = at.node = at.cp = at.l = 0;
+            if (g >= n_chunks) return at;
             while (seg < n_seg - 1 && g >= __builtin_amdgcn_readfirstlane(s_pre[seg + 1])) ++seg;
             const unsigned i = (unsigned)(g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * RT_BLOCK + threadIdx.x;   // pair of the segment
-            bool queue = false; int item = 0, qnode = 0, qcp = 0;
-            if (i < (unsigned)__builtin_amdgcn_readfirstlane((int)s_items[seg])) {
-                int dense, l;
-                if (L == 1) { dense = (int)i; l = 0; } else { dense = (int)(i / (unsigned)L); l = (int)(i % (unsigned)L); }
-                const int mul = __builtin_amdgcn_readfirstlane(s_mul[seg]);
-                int node_local = dense, cp = 0;
-                if (mul > 1) {
-                    if ((mul & (mul - 1)) == 0) { node_local = dense >> (31 - __clz(mul)); cp = dense & (mul - 1); }
-                    else { node_local = dense / mul; cp = dense - node_local * mul; }
-                }
-                const int node = __builtin_amdgcn_readfirstlane(s_nbase[seg]) + node_local;
-                item = (__builtin_amdgcn_readfirstlane(s_sbase[seg]) + dense) * L + l;
-                qnode = node; qcp = cp;
-                const float4 a = w.n_a[node], b = w.n_b[node];
+            if (i >= (unsigned)__builtin_amdgcn_readfirstlane((int)s_items[seg])) return at;
+            int dense;
+            if (L == 1) { dense = (int)i; at.l = 0; } else { dense = (int)(i / (unsigned)L); at.l = (int)(i % (unsigned)L); }
+            const int mul = __builtin_amdgcn_readfirstlane(s_mul[seg]);
+            int node_local = dense;
+            if (mul > 1) {
+                if ((mul & (mul - 1)) == 0) { node_local = dense >> (31 - __clz(mul)); at.cp = dense & (mul - 1); }
+                else { node_local = dense / mul; at.cp = dense - node_local * mul; }
+            }
+            at.node = __builtin_amdgcn_readfirstlane(s_nbase[seg]) + node_local;
+            at.item = (__builtin_amdgcn_readfirstlane(s_sbase[seg]) + dense) * L + at.l;
+            a = w.n_a[at.node]; b = w.n_b[at.node];
+            at.valid = true;
+            return at;
+        };
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a, a_next = a, b_next = a;
+        PairAt cur = locate((int)blockIdx.x, a, b);
+        for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
+            const PairAt nxt = locate(g + (int)gridDim.x, a_next, b_next);
+            bool queue = false; const int item = cur.item, qnode = cur.node; int qcp = cur.cp;
+            if (cur.valid) {
+                const int l = cur.l;
                 // a node of a level with several slots per node has either one copy or all of them (top bit of the id word)
-                if (cp == 0 || f2i(b.w) < 0) {
+                if (cur.cp == 0 || f2i(b.w) < 0) {
                     const float4 lt = (L == 1) ? light0 : sc.lights[l];
                     if (!faces_light(a, b, lt)) out[item] = 0;
                     else if (!SUB && MODE != 0 && cull) {
@@ -1460,19 +1642,18 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                                                       f.cull_own ? (f2i(b.w) & 0x7fffffff) : -1, mk(b.x, b.y, b.z), f.cull_umbra != 0);
                         const int what = cone_outcome(sc, s_nodes, s_leaves, f.use_bvh != 0, cs);
                         if (what == CONE_TRACE) queue = true; else out[item] = what == CONE_NONE ? SS : 0;
-#ifdef RT_SHADOW_HIST
-                        qcp |= (int)(cs.may & 7u) << 12;
-#endif
+                        if (masks) qcp |= (int)((cs.may & 0xffffu) << 16);
                     }
                     else queue = true;
                 }
             }
+            cur = nxt; a = a_next; b = b_next;
             {
                 const unsigned long long m = __ballot(queue);
                 int base = 0;
                 if (__lane_id() == 0 && m) base = atomicAdd(&s_qn, __popcll(m));
                 base = __shfl(base, 0, 64);
-                if (queue) { const int at = base + __popcll(m & ((1ull << __lane_id()) - 1ull)); s_q[at] = item; s_qnode[at] = qnode; s_qcp[at] = (unsigned short)qcp; }
+                if (queue) { const int at = base + __popcll(m & ((1ull << __lane_id()) - 1ull)); s_q[at] = item; s_qnode[at] = qnode; s_qcp[at] = (unsigned)qcp; }
             }
             __syncthreads();
             int qn = s_qn;
@@ -1554,10 +1735,10 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                                 if (my < n_queued_rays) {
                                     pr = my >> ss_shift;
                                     const int j = my & (SS - 1), it = s_q[pr];
-                                    const int node = s_qnode[pr], cp = (int)s_qcp[pr];
+                                    const int node = s_qnode[pr], cp = (int)(s_qcp[pr] & 0xffffu);
                                     const int l = (L == 1) ? 0 : it % L;
                                     ++n_rays;
-                                    lightDist = make_sample_ray(node, cp, l, j, w.n_a[node], (L == 1) ? light0 : sc.lights[l], sr);
+                                    lightDist = make_sample_ray(node, false, 0u, cp, l, j, w.n_a[node], (L == 1) ? light0 : sc.lights[l], sr);
                                     q = make_sub_ray(sc, sr);
                                     const float ax = fabsf(sr.d.x), ay = fabsf(sr.d.y), az = fabsf(sr.d.z);
                                     fast_ok = ax > 1e-18f && ax < 1e18f && ay > 1e-18f && ay < 1e18f && az > 1e-18f && az < 1e18f;
@@ -1639,45 +1820,18 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                 __syncthreads();
                 continue;
             }
-            // (phase 1 traces nothing itself unless the queue in memory is full)
-            bool trace_here = phase != 1, empty_it = last;
-            if (!SUB && phase == 1 && (qn > QCAP - RT_BLOCK || (last && qn > 0))) {
-                // The queue goes to memory: one atomic per workgroup and queue-full (the regions spread those over several
-                // counters), the entries behind it.  What a full region cannot take stays here and is traced below.
-                if (threadIdx.x == 0) {
-                    const int rg = (int)(blockIdx.x % (unsigned)w.regions);
-                    const int at = atomicAdd(&w.ctr[RT_CTR_SHADOWQ(sq_k, rg)], qn);
-                    s_gfit = max(0, min(qn, w.sq_rcap - at));
-                    s_gbase = (sq_k * w.regions + rg) * w.sq_rcap + at;
-                }
-                __syncthreads();
-                const int fit = s_gfit;
-                int4* __restrict__ dst = w.sq + (size_t)s_gbase;
-                for (int k = threadIdx.x; k < fit; k += blockDim.x) dst[k] = make_int4(s_q[k], s_qnode[k], (int)s_qcp[k], 0);
-                if (fit < qn) {
-                    // (the rest moves to the front of the queue)
-                    int mq[QCAP / RT_BLOCK], mn[QCAP / RT_BLOCK]; unsigned short mc[QCAP / RT_BLOCK];
-#pragma unroll
-                    for (int u = 0; u < QCAP / RT_BLOCK; ++u) { const int k = fit + u * RT_BLOCK + (int)threadIdx.x; if (k < qn) { mq[u] = s_q[k]; mn[u] = s_qnode[k]; mc[u] = s_qcp[k]; } }
-                    __syncthreads();
-#pragma unroll
-                    for (int u = 0; u < QCAP / RT_BLOCK; ++u) { const int k = u * RT_BLOCK + (int)threadIdx.x; if (fit + k < qn) { s_q[k] = mq[u]; s_qnode[k] = mn[u]; s_qcp[k] = mc[u]; } }
-                }
-                __syncthreads();
-                qn -= fit;
-                trace_here = empty_it = qn > 0;
-            }
-            while (trace_here && (qn >= pairs_per_pass || (empty_it && qn > 0))) {     // after the last chunk the queue is emptied
+            while (qn >= pairs_per_pass || (last && qn > 0)) {           // after the last chunk the queue is emptied
                 const int take = min(qn, pairs_per_pass), first = qn - take;
                 const int k = (int)(threadIdx.x >> ss_shift), j = (int)(threadIdx.x & (unsigned)(SS - 1));
                 const bool active = k < take;
                 bool unblocked = false; int it = 0;
                 if (active) {
                     it = s_q[first + k];
-                    const int node = s_qnode[first + k], cp = (int)s_qcp[first + k] & 0xfff;
+                    const int node = s_qnode[first + k];
+                    const unsigned cpm = s_qcp[first + k];
                     const int l = (L == 1) ? 0 : it % L;
                     ++n_rays;
-                    unblocked = sample_unblocked(node, cp, l, j, w.n_a[node], (L == 1) ? light0 : sc.lights[l]);
+                    unblocked = sample_unblocked(node, false, 0u, (int)(cpm & 0xffffu), l, j, w.n_a[node], (L == 1) ? light0 : sc.lights[l], cpm >> 16);
                 }
                 const unsigned long long m = __ballot(active && unblocked);
                 if (active && j == 0) {
@@ -1687,7 +1841,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
 #ifdef RT_SHADOW_HIST
                     // development: how many traced pairs end fully blocked / partly / fully unblocked (level 0; deeper levels)
                     { const int cnt = __popcll(grp); atomicAdd(&w.stats[RT_S_WALK + (lv_begin ? 20 : 16) + (cnt == 0 ? 0 : cnt == SS ? 2 : 1)], 1ull);
-                      const int may3 = (int)s_qcp[first + k] >> 12;
+                      const int may3 = (int)(s_qcp[first + k] >> 16) & 7;
                       if (cnt == SS) atomicAdd(&w.stats[RT_S_WALK + may3], 1ull); else if (cnt == 0) atomicAdd(&w.stats[RT_S_WALK + 8 + may3], 1ull); else atomicAdd(&w.stats[RT_S_WALK + 24 + may3], 1ull); }
 #endif
                 }
@@ -1717,7 +1871,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         const float4 lt = (L == 1) ? light0 : sc.lights[l];
         if (!faces_light(a, b, lt)) continue;                            // the host zeroed the counts for this layout
         ++n_rays;
-        if (sample_unblocked(node, cp, l, j, a, lt)) atomicAdd(&out[(__builtin_amdgcn_readfirstlane(s_sbase[seg]) + dense) * L + l], 1);
+        if (sample_unblocked(node, false, 0u, cp, l, j, a, lt, 0u)) atomicAdd(&out[(__builtin_amdgcn_readfirstlane(s_sbase[seg]) + dense) * L + l], 1);
     }
     if (f.count_stats) block_stat_add(&w.stats[RT_S_SHADOW], n_rays, s_tmp);
 }

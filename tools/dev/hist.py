@@ -8,7 +8,7 @@ flags = sys.argv[1].split()
 cfg, _ = api.parse_args(flags)
 ls = api.LoadedScene(cases.reference_scene(1920, 1080), cfg, str(cases.TEXTURES))
 r = api.Renderer(0, 16 << 30)
-r.set_option("walk_stats", 1); r.set_option("overlap", 0)
+r.set_option("walk_stats", 1); r.set_option("overlap", 0); r.set_option("shadow_queue", 0)
 r.upload(ls, with_bvh=True)
 out = torch.empty(r.out_bytes(), dtype=torch.uint8, device="cuda")
 st = r.render_device(cfg, out.data_ptr(), want_stats=True)
