@@ -1901,17 +1901,28 @@ DEVI void store_pixel(const DevFrame& f, unsigned char* __restrict__ out, int ti
 // then the parent's combination of its children's colours with both clamps (raytracer.cpp:436-503).  Level 0
 // adds the result to the pixel's running sum (raytracer.cpp:154).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(DevScene sc, DevFrame f, DevWork w, int level) {
+// GROUP: copies a lane has in flight together: 4 for levels whose nodes have copies, 1 (a leaner kernel: more wavefronts
+// resident) for levels of one slot per node
+template <int GROUP>
+__global__ __launch_bounds__(RT_BLOCK, GROUP > 1 ? RT_SHADE_WAVES : RT_SHADE_WAVES + 1) void k_shade(DevScene sc, DevFrame f, DevWork w, int level) {
     __shared__ unsigned long long s_tmp[RT_BLOCK / 64];
     // chunks of RT_BLOCK hits inside the level's regions, as in k_extend
-    __shared__ int s_pre[RT_REGIONS + 1], s_cnt[RT_REGIONS];
+    __shared__ int s_pre[RT_REGIONS + 1], s_cnt[RT_REGIONS], s_per_slot;
     if (threadIdx.x == 0) {
         int acc = 0, n[RT_REGIONS];
 #pragma unroll
         for (int rg = 0; rg < RT_REGIONS; ++rg) n[rg] = w.ctr[RT_CTR_NODE(level, rg)];          // unused regions' counters stay 0
+        // A level whose nodes have several copies: a lane per node that walks its copies forms the hit's lighting terms
+        // once, but waits for its copies' loads group after group; a lane per SLOT repeats those terms for every copy and
+        // has nothing to wait for twice.  The second wins while the whole level is one round of the launch's lanes.
+        int total = 0;
+#pragma unroll
+        for (int rg = 0; rg < RT_REGIONS; ++rg) total += min(n[rg], w.node_rcap[level]);
+        const int per_slot = (w.slot_mul[level] > 1 && (long long)total * w.slot_mul[level] <= (long long)gridDim.x * RT_BLOCK) ? w.slot_mul[level] : 1;
+        s_per_slot = per_slot;
 #pragma unroll
         for (int rg = 0; rg < RT_REGIONS; ++rg) {
-            const int m = min(n[rg], w.node_rcap[level]);
+            const int m = min(n[rg], w.node_rcap[level]) * per_slot;
             s_cnt[rg] = m; s_pre[rg] = acc; acc += (m + RT_BLOCK - 1) / RT_BLOCK;
         }
         s_pre[RT_REGIONS] = acc;
@@ -1923,6 +1934,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(DevScene sc,
     const int* __restrict__ sh = (const int*)w.shadow;
     const V3 cam = mk(f.cam_loc[0], f.cam_loc[1], f.cam_loc[2]);
     const int mul = w.slot_mul[level], mul_child = w.slot_mul[level + 1];
+    const bool slot_lanes = s_per_slot > 1;
     const float inv_gr = 1.0f / (float)f.gr_samples;                     // raytracer.cpp:436-439
     unsigned long long n_shaded = 0;
     int seg = 0;
@@ -1930,7 +1942,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(DevScene sc,
         while (seg < w.regions - 1 && g >= __builtin_amdgcn_readfirstlane(s_pre[seg + 1])) ++seg;
         const int k = (g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * RT_BLOCK + (int)threadIdx.x;
         if (k >= __builtin_amdgcn_readfirstlane(s_cnt[seg])) continue;
-        const int node = w.node_off[level] + seg * w.node_rcap[level] + k;
+        int k_node = k, my_cp = 0;
+        if (slot_lanes) {
+            if ((mul & (mul - 1)) == 0) { k_node = k >> (31 - __clz(mul)); my_cp = k & (mul - 1); }
+            else { k_node = k / mul; my_cp = k - k_node * mul; }
+        }
+        const int node = w.node_off[level] + seg * w.node_rcap[level] + k_node;
         const int slot0 = w.slot_off[level] + (node - w.node_off[level]) * mul;      // slot of the node's copy 0
         const bool has_children = level < f.max_depth;
         float4 a = w.n_a[node], b = w.n_b[node];
@@ -1958,9 +1975,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(DevScene sc,
         const bool bundle = (packed >> 29) & 1;
         const int n_reflect = bundle ? (packed & 0x1fff) : (packed & 0x1fffffff);
         const int copies = bundle ? ((packed >> 13) & 0xffff) : 1;
+        if (my_cp >= copies) continue;                                   // (a node with one copy in a level of several slots per node)
         const bool refract = (packed >> 30) & 1;
         const float reflectivity = m2.z;
-        n_shaded += (unsigned)copies;
+        n_shaded += slot_lanes ? 1u : (unsigned)copies;
         // slot of copy 0 of a child node (children live one level down)
         auto child_slot = [&](int ch) { return w.slot_off[level + 1] + (ch - w.node_off[level + 1]) * mul_child; };
         int refl_slot = -1, refr_slot = -1;                              // bundles and single reflections: one child node
@@ -1989,12 +2007,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(DevScene sc,
             const bool first_light = l == 0, last_light = l >= L - 1;
             // copies four at a time: everything a group reads is loaded before anything is stored, so the loads of a
             // group are in flight together (a lane with 16 copies otherwise waits for sixteen round trips in a row)
-            for (int cp0 = 0; cp0 < copies; cp0 += 4) {
-                int cnt4[4]; float4 own4[4], refl4[4], refr4[4];
+            // (a lane per slot: this lane's copy only)
+            const int cp_end = slot_lanes ? my_cp + 1 : copies;
+            for (int cp0 = my_cp; cp0 < cp_end; cp0 += GROUP) {
+                int cnt4[GROUP]; float4 own4[GROUP], refl4[GROUP], refr4[GROUP];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < GROUP; ++u) {
                     const int cp = cp0 + u, slot = slot0 + cp;
-                    const bool on = cp < copies;
+                    const bool on = cp < cp_end;
                     cnt4[u] = (on && L > 0) ? sh[slot * L + l] : 0;
                     own4[u] = (on && !first_light) ? w.n_col[slot] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     refl4[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); refr4[u] = refl4[u];
@@ -2004,9 +2024,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade(DevScene sc,
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < GROUP; ++u) {
                     const int cp = cp0 + u, slot = slot0 + cp;
-                    if (cp >= copies) break;
+                    if (cp >= cp_end) break;
                     V3 col = first_light ? mk(ka * mat.x, ka * mat.y, ka * mat.z) : mk(own4[u].x, own4[u].y, own4[u].z);
                     if (L > 0) {
                         const int cnt = cnt4[u];
@@ -2369,7 +2389,8 @@ void rt_launch_sort_keys(hipStream_t s, const DevScene& sc, const DevWork& w, in
 }
 
 void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid) {
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, s, sc, f, w, level);
+    if (w.slot_mul[level] > 1) hipLaunchKernelGGL(k_shade<4>, dim3(grid), dim3(RT_BLOCK), 0, s, sc, f, w, level);
+    else hipLaunchKernelGGL(k_shade<1>, dim3(grid), dim3(RT_BLOCK), 0, s, sc, f, w, level);
 }
 
 void rt_launch_begin_frame(hipStream_t s, const DevWork& w, void* zero, size_t zero_bytes, bool zero_stats) {
