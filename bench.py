@@ -436,7 +436,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     st = r.render_device(cfg, block.data_ptr(), want_stats=True)     # ray counts (the counting kernel variants)
     heavy = st.ms_total > 150.0                                      # a frame of hundreds of ms: no extra frames beyond the timed ones
     note(f"first frame {st.ms_total:.1f} ms, {st.total_rays()} rays, {st.batches} batches")
-    shadow_all = shadow_no_cone = None
+    shadow_all = shadow_no_cone = shadow_no_umbra = None
     if heavy:
         steps = min(steps, 3); warmup = min(warmup, 1)
     if detail and heavy:
@@ -461,7 +461,9 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
         shadow_all = r.render_device(cfg, block.data_ptr(), want_stats=True).shadow_rays
         r.set_option("skip_unlit", 1)                                # ... and the cone test of soft shadows (tiny scenes)
         shadow_no_cone = r.render_device(cfg, block.data_ptr(), want_stats=True).shadow_rays
-        r.set_option("cull_cones", 1)
+        r.set_option("cull_cones", 1); r.set_option("cull_umbra", 0)  # ... and the pairs in full shadow of one sphere or cube
+        shadow_no_umbra = r.render_device(cfg, block.data_ptr(), want_stats=True).shadow_rays
+        r.set_option("cull_umbra", 1)
         for _ in range(4):
             r.render_device(cfg, block.data_ptr())
         r.set_option("count_rays", 0)                                # stage times with the kernels the timed frames run
@@ -546,7 +548,9 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
                                   "shadow_not_traced_because_the_surface_faces_away_from_the_light":
                                       (shadow_all - shadow_no_cone) if (world == 1 and shadow_all is not None) else None,
                                   "shadow_not_traced_because_no_sample_ray_of_the_pair_can_reach_a_primitive":
-                                      (shadow_no_cone - st.shadow_rays) if (world == 1 and shadow_no_cone is not None) else None},
+                                      (shadow_no_cone - shadow_no_umbra) if (world == 1 and shadow_no_cone is not None) else None,
+                                  "shadow_not_traced_because_every_sample_ray_of_the_pair_is_certain_to_be_blocked":
+                                      (shadow_no_umbra - st.shadow_rays) if (world == 1 and shadow_no_umbra is not None) else None},
                "lit_fraction": lit, "image_crc32": crc, "stats": st}
     torch.cuda.synchronize(dev)
     torch.cuda.set_stream(torch.cuda.default_stream(dev))      # the contexts' streams die with them
@@ -638,6 +642,10 @@ def main():
             "value": head["value"], "unit": "rays/s", "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"],
             "ms_per_step": head["ms_per_step"], "frame_ms_alone": head["frame_ms_alone"],
             "value_one_frame_at_a_time": head["rays_total"] / (head["frame_ms_alone"] / 1e3),
+            "frames_per_s": 1e3 / head["ms_per_step"],
+            # the rays the reference traces for the same frames (raytracer.cpp:400-432, 534-571 count every sample ray and every
+            # identical reflection ray): what a caller that switches libraries gets per second, not what this library traces
+            "reference_rays_per_s": head["rays_per_frame"]["as_the_reference_would_trace_them"] / (head["ms_per_step"] / 1e3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic: the reference's own ASCII/scene.json (committed as a fixture), no dataset" if wl["scene"] == "ref"
                     else f"the reference's Blend/{wl['scene'][6:]}.blend exported to scene.json text (committed as a fixture)" if wl["scene"].startswith("blend:")
@@ -652,7 +660,9 @@ def main():
                        "soft_shadow_sampling": "the first reflection of every path is recorded gr_samples times (each copy draws its own shadow "
                                                "samples, as the reference's identical rays do; one traced ray per bundle); deeper reflections once",
                        "value_counts": "traced rays only: shadow rays whose outcome is certain without tracing (surface facing away from the light; "
-                                       "no sample ray of the pair can reach a primitive) and the identical copies of a reflection ray are not counted",
+                                       "no sample ray of the pair can reach a primitive; every sample ray of the pair is certain to be blocked) and "
+                                       "the identical copies of a reflection ray are not counted - a rule that leaves more rays untraced lowers "
+                                       "`value` while it shortens the frame: compare frames (ms_per_step, frame_ms_alone) across builds, not rays",
                        "rays_per_frame": head["rays_per_frame"], "lit_fraction": head["lit_fraction"], "image_crc32": head["image_crc32"]},
             "roofline": roofline(st, args.workload, wl["scene"] != "random"),
         }

@@ -1597,7 +1597,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
                     // the primary hits are final: their shadow rays start now, beside the deeper levels' tracing
                     hipStream_t ss = overlap ? c->aux_stream : s;
                     if (overlap) { RT_HIP(c, hipEventRecord(c->ev_fork, s)); RT_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0)); }
-                    tm->begin(ST_SHADOW); rt_launch_shadow(ss, c->scene, f, w, 0, 0, g_shadow, g_drain); tm->end();
+                    tm->begin(ST_SHADOW); tm->launches[ST_SHADOW] += rt_launch_shadow(ss, c->scene, f, w, 0, 0, g_shadow, g_drain) - 1; tm->end();
                     if (overlap) RT_HIP(c, hipEventRecord(c->ev_join, c->aux_stream));
                 }
                 if (level == 1 && fork1) {
@@ -1605,11 +1605,11 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
                     // few per cent of a frame's hits): the launches that trace those, and the shading of the deep levels,
                     // wait on memory most of the time and run beside the shadow rays' arithmetic
                     RT_HIP(c, hipEventRecord(c->ev_fork2, s)); RT_HIP(c, hipStreamWaitEvent(c->aux_stream2, c->ev_fork2, 0));
-                    rt_launch_shadow(c->aux_stream2, c->scene, f, w, 1, 1, g_shadow, g_drain);
+                    tm->launches[ST_SHADOW] += rt_launch_shadow(c->aux_stream2, c->scene, f, w, 1, 1, g_shadow, g_drain);
                     RT_HIP(c, hipEventRecord(c->ev_join2, c->aux_stream2));
                 }
             }
-            if (L > 0) { tm->begin(ST_SHADOW); rt_launch_shadow(s, c->scene, f, w, fork1 ? 2 : (split ? 1 : 0), D, g_shadow, g_drain); tm->end(); }
+            if (L > 0) { tm->begin(ST_SHADOW); tm->launches[ST_SHADOW] += rt_launch_shadow(s, c->scene, f, w, fork1 ? 2 : (split ? 1 : 0), D, g_shadow, g_drain) - 1; tm->end(); }
             for (int level = D; level >= 0; --level) {
                 // only the shading of the levels whose shadow rays were forked needs those launches; the deeper levels
                 // resolve beside them

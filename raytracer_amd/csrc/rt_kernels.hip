@@ -1369,6 +1369,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     __shared__ unsigned s_items[MAX_SEG];                               // shadow rays of the segment
     __shared__ int s_nbase[MAX_SEG];                                    // node index of the segment's first hit
     __shared__ int s_sbase[MAX_SEG];                                    // slot of that node's copy 0
+    __shared__ int s_cstride[MAX_SEG];                                  // slots between two copies of a node
     __shared__ int s_mul[MAX_SEG];                                      // slots per node in the segment
     const int L = sc.n_lights;
     constexpr bool FAST = MODE == 2;
@@ -1391,6 +1392,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         s_nbase[sg] = w.node_off[lv] + rg * w.node_rcap[lv];
         s_sbase[sg] = w.slot_off[lv] + rg * w.node_rcap[lv] * w.slot_mul[lv];
         s_mul[sg] = w.slot_mul[lv];
+        s_cstride[sg] = w.node_rcap[lv];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1520,9 +1522,9 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         // (the regions spread those over several counters), no workgroup-wide step.  What a full region cannot take is
         // traced here, lane by lane.
         float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a, a_next = a, b_next = a;
-        struct NodeAt { bool valid; int item0, node, l, mul; };
+        struct NodeAt { bool valid; int item0, node, l, mul, cstep; };     // cstep: from one copy's count to the next
         auto locate = [&](int g, float4& ra, float4& rb) -> NodeAt {
-            NodeAt at; at.valid = false; at.item0 = at.node = at.l = 0; at.mul = 1;
+            NodeAt at; at.valid = false; at.item0 = at.node = at.l = at.cstep = 0; at.mul = 1;
             if (g >= n_chunks) return at;
             while (seg < n_seg - 1 && g >= __builtin_amdgcn_readfirstlane(s_pre[seg + 1])) ++seg;
             const unsigned i = (unsigned)(g - __builtin_amdgcn_readfirstlane(s_pre[seg])) * RT_BLOCK + threadIdx.x;   // (node, light) of the segment
@@ -1531,7 +1533,8 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
             if (L == 1) { node_local = (int)i; at.l = 0; } else { node_local = (int)(i / (unsigned)L); at.l = (int)(i % (unsigned)L); }
             at.mul = __builtin_amdgcn_readfirstlane(s_mul[seg]);
             at.node = __builtin_amdgcn_readfirstlane(s_nbase[seg]) + node_local;
-            at.item0 = (__builtin_amdgcn_readfirstlane(s_sbase[seg]) + node_local * at.mul) * L + at.l;
+            at.item0 = (__builtin_amdgcn_readfirstlane(s_sbase[seg]) + node_local) * L + at.l;
+            at.cstep = __builtin_amdgcn_readfirstlane(s_cstride[seg]) * L;
             ra = w.n_a[at.node]; rb = w.n_b[at.node];
             at.valid = true;
             return at;
@@ -1556,7 +1559,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                     if (masks) may16 = cs.may & 0xffffu;
                 }
                 if (what == CONE_TRACE) n_push = ncp;
-                else for (int cp = 0; cp < ncp; ++cp) out[cur.item0 + cp * L] = what == CONE_NONE ? SS : 0;
+                else for (int cp = 0; cp < ncp; ++cp) out[cur.item0 + cp * cur.cstep] = what == CONE_NONE ? SS : 0;
             }
             const unsigned long long m1 = __ballot(n_push == 1), mm = __ballot(n_push > 1);
             if (m1 | mm) {
@@ -1572,12 +1575,12 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                     for (int cp = 0; cp < n_push; ++cp) {
                         if (at + cp < w.sq_rcap) {
                             int4* __restrict__ e = qbase + 2 * (size_t)(at + cp);
-                            e[0] = make_int4(cur.item0 + cp * L, cp | (int)(may16 << 16), path, f2i(a.w));
+                            e[0] = make_int4(cur.item0 + cp * cur.cstep, cp | (int)(may16 << 16), path, f2i(a.w));
                             *(float4*)(e + 1) = make_float4(a.x, a.y, a.z, 0.0f);
                         } else {
                             int cnt = 0;
                             for (int j = 0; j < SS; ++j) { ++n_rays; cnt += sample_unblocked(cur.node, true, (uint32_t)path, cp, cur.l, j, a, lt, may16) ? 1 : 0; }
-                            out[cur.item0 + cp * L] = cnt;
+                            out[cur.item0 + cp * cur.cstep] = cnt;
                         }
                     }
                 }
@@ -1621,7 +1624,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                 else { node_local = dense / mul; at.cp = dense - node_local * mul; }
             }
             at.node = __builtin_amdgcn_readfirstlane(s_nbase[seg]) + node_local;
-            at.item = (__builtin_amdgcn_readfirstlane(s_sbase[seg]) + dense) * L + at.l;
+            at.item = (__builtin_amdgcn_readfirstlane(s_sbase[seg]) + at.cp * __builtin_amdgcn_readfirstlane(s_cstride[seg]) + node_local) * L + at.l;
             a = w.n_a[at.node]; b = w.n_b[at.node];
             at.valid = true;
             return at;
@@ -1871,7 +1874,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         const float4 lt = (L == 1) ? light0 : sc.lights[l];
         if (!faces_light(a, b, lt)) continue;                            // the host zeroed the counts for this layout
         ++n_rays;
-        if (sample_unblocked(node, false, 0u, cp, l, j, a, lt, 0u)) atomicAdd(&out[(__builtin_amdgcn_readfirstlane(s_sbase[seg]) + dense) * L + l], 1);
+        if (sample_unblocked(node, false, 0u, cp, l, j, a, lt, 0u)) atomicAdd(&out[(__builtin_amdgcn_readfirstlane(s_sbase[seg]) + cp * __builtin_amdgcn_readfirstlane(s_cstride[seg]) + node_local) * L + l], 1);
     }
     if (f.count_stats) block_stat_add(&w.stats[RT_S_SHADOW], n_rays, s_tmp);
 }
@@ -1934,6 +1937,7 @@ __global__ __launch_bounds__(RT_BLOCK, GROUP > 1 ? RT_SHADE_WAVES : RT_SHADE_WAV
     const int* __restrict__ sh = (const int*)w.shadow;
     const V3 cam = mk(f.cam_loc[0], f.cam_loc[1], f.cam_loc[2]);
     const int mul = w.slot_mul[level], mul_child = w.slot_mul[level + 1];
+    const int cstride = w.node_rcap[level], cstride_child = w.node_rcap[level + 1];
     const bool slot_lanes = s_per_slot > 1;
     const float inv_gr = 1.0f / (float)f.gr_samples;                     // raytracer.cpp:436-439
     unsigned long long n_shaded = 0;
@@ -1948,7 +1952,8 @@ __global__ __launch_bounds__(RT_BLOCK, GROUP > 1 ? RT_SHADE_WAVES : RT_SHADE_WAV
             else { k_node = k / mul; my_cp = k - k_node * mul; }
         }
         const int node = w.node_off[level] + seg * w.node_rcap[level] + k_node;
-        const int slot0 = w.slot_off[level] + (node - w.node_off[level]) * mul;      // slot of the node's copy 0
+        // slot of the node's copy 0; copy cp sits cstride slots further (a region's slots: copy by copy, each node by node)
+        const int slot0 = w.slot_off[level] + seg * mul * cstride + k_node;
         const bool has_children = level < f.max_depth;
         float4 a = w.n_a[node], b = w.n_b[node];
         const float4 c = (has_children || f.soft_shadows) ? w.n_c[node] : make_float4(i2f(-1), 0.0f, 0.0f, 0.0f);   // (not written otherwise, see k_extend)
@@ -1980,7 +1985,12 @@ __global__ __launch_bounds__(RT_BLOCK, GROUP > 1 ? RT_SHADE_WAVES : RT_SHADE_WAV
         const float reflectivity = m2.z;
         n_shaded += slot_lanes ? 1u : (unsigned)copies;
         // slot of copy 0 of a child node (children live one level down)
-        auto child_slot = [&](int ch) { return w.slot_off[level + 1] + (ch - w.node_off[level + 1]) * mul_child; };
+        auto child_slot = [&](int ch) {
+            const int x = ch - w.node_off[level + 1];
+            if (mul_child <= 1) return w.slot_off[level + 1] + x;
+            const int rg_c = x / cstride_child;
+            return w.slot_off[level + 1] + rg_c * mul_child * cstride_child + (x - rg_c * cstride_child);
+        };
         int refl_slot = -1, refr_slot = -1;                              // bundles and single reflections: one child node
         if (has_children) {
             if ((n_reflect == 1 || bundle) && n_reflect > 0) { const int ch = w.link[first]; if (ch >= 0) refl_slot = child_slot(ch); }
@@ -2013,19 +2023,19 @@ __global__ __launch_bounds__(RT_BLOCK, GROUP > 1 ? RT_SHADE_WAVES : RT_SHADE_WAV
                 int cnt4[GROUP]; float4 own4[GROUP], refl4[GROUP], refr4[GROUP];
 #pragma unroll
                 for (int u = 0; u < GROUP; ++u) {
-                    const int cp = cp0 + u, slot = slot0 + cp;
+                    const int cp = cp0 + u, slot = slot0 + cp * cstride;
                     const bool on = cp < cp_end;
                     cnt4[u] = (on && L > 0) ? sh[slot * L + l] : 0;
                     own4[u] = (on && !first_light) ? w.n_col[slot] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     refl4[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); refr4[u] = refl4[u];
                     if (on && last_light && has_children) {
-                        if (n_reflect == 1 && refl_slot >= 0) refl4[u] = w.n_col[refl_slot + cp];
-                        if (refr_slot >= 0) refr4[u] = w.n_col[refr_slot + cp];
+                        if (n_reflect == 1 && refl_slot >= 0) refl4[u] = w.n_col[refl_slot + cp * cstride_child];
+                        if (refr_slot >= 0) refr4[u] = w.n_col[refr_slot + cp * cstride_child];
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < GROUP; ++u) {
-                    const int cp = cp0 + u, slot = slot0 + cp;
+                    const int cp = cp0 + u, slot = slot0 + cp * cstride;
                     if (cp >= cp_end) break;
                     V3 col = first_light ? mk(ka * mat.x, ka * mat.y, ka * mat.z) : mk(own4[u].x, own4[u].y, own4[u].z);
                     if (L > 0) {
@@ -2048,7 +2058,7 @@ __global__ __launch_bounds__(RT_BLOCK, GROUP > 1 ? RT_SHADE_WAVES : RT_SHADE_WAV
                             } else if (bundle) {
                                 // one traced ray whose node holds this hit's n_reflect children as its copies
                                 for (int s2 = 0; s2 < n_reflect; ++s2) {
-                                    if (refl_slot >= 0) { const float4 q = w.n_col[refl_slot + cp * n_reflect + s2]; rc = rc + mk(q.x, q.y, q.z); }
+                                    if (refl_slot >= 0) { const float4 q = w.n_col[refl_slot + (cp * n_reflect + s2) * cstride_child]; rc = rc + mk(q.x, q.y, q.z); }
                                     else rc = rc + mk(0.0f, 0.0f, 0.0f);
                                 }
                             } else {
@@ -2366,7 +2376,7 @@ void rt_launch_primary_shaded(hipStream_t s, const DevScene& sc, const DevFrame&
     else rt_launch_fused_part0(s, sc, f, w, grid, lds, ldsp);
 }
 
-void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, int grid_drain) {
+int rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, int grid_drain) {
     const size_t lds = bvh_lds_bytes(sc, f, !f.use_bvh);
     const int mode = !f.soft_shadows ? 0 : (f.fast_samples ? 2 : 1);  // hard shadows are deterministic: always exact
     const int sub = scene_sub(sc);
@@ -2379,7 +2389,9 @@ void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, cons
         const int sq_k = lv_begin < RT_SHADOWQ_LAUNCHES - 1 ? lv_begin : RT_SHADOWQ_LAUNCHES - 1;
         rt_launch_shadow_part0(s, sc, f, w, lv_begin, lv_end, grid, lds, ldsp, mode, 1, sq_k);
         rt_launch_shadow_part0(s, sc, f, w, lv_begin, lv_end, grid_drain, lds, ldsp, mode, 2, sq_k);
+        return 2;
     } else rt_launch_shadow_part0(s, sc, f, w, lv_begin, lv_end, grid, lds, ldsp, mode, 0, 0);
+    return 1;
 }
 
 void rt_launch_sort_keys(hipStream_t s, const DevScene& sc, const DevWork& w, int level, unsigned* keys, unsigned* slots) {

@@ -125,7 +125,8 @@ struct DevFrame {
 // A node stands for `copies` identical hits of the reference (a bundle: its gr_samples identical reflection rays, and
 // everything below them) that differ only in the shadow samples they draw.  What differs per copy lives in SLOTS:
 //   n_col[slot] = resolved colour (r, g, b, 0)     shadow[slot * lights + light] = unblocked samples
-//   slot of copy cp of a node of `level` = slot_off[level] + (node - node_off[level]) * slot_mul[level] + cp
+//   slot of copy cp of the k-th node of region rg of `level` = slot_off[level] + (rg * slot_mul[level] + cp) * node_rcap[level] + k
+//   (copy by copy inside a region: lanes that hold neighbouring nodes touch neighbouring slots whatever the copy)
 // with slot_mul = 1 everywhere without bundles (slot == node), and gr_samples for the levels >= 1 of a frame with bundles
 // (a node there has 1 or gr_samples copies; copy cp's path id is the node's for cp = 0, else mix32(id + 0x9E3779B1 * cp)).
 // Every level's part of the node arena and of the ray queue is cut into `regions` (<= RT_REGIONS) regions of equal capacity, each
@@ -202,7 +203,8 @@ static inline int rt_sub_stack_entries(int depth) { return 3 * ((depth + 1) / 2)
 // kernel launchers (rt_kernels.hip)
 void rt_launch_extend(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);
 void rt_launch_primary_shaded(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int grid);
-void rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, int grid_drain);
+// (returns the number of kernels launched: classification and tracing are two where the queue of pairs is in use)
+int rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, int grid_drain);
 void rt_launch_sort_keys(hipStream_t s, const DevScene& sc, const DevWork& w, int level, unsigned* keys, unsigned* slots);
 void rt_launch_shade(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int level, int grid);
 void rt_launch_begin_frame(hipStream_t s, const DevWork& w, void* zero, size_t zero_bytes, bool zero_stats);
