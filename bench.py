@@ -386,8 +386,10 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
     ctxs = [(r, stream, block)]
     for _ in range(P - 1):
         r2 = new_renderer()
-        if device_scene:
-            r2.adopt_from(r)                          # the rank's other contexts copy the first one's arrays on the device
+        if os.environ.get("RT_BENCH_SHARE", "1") != "0":
+            r2.share_from(r)                          # the rank's other contexts render from the first one's arrays: one copy of the scene in the caches
+        elif device_scene:
+            r2.adopt_from(r)
         else:
             r2.upload(ls, with_bvh=bool(cfg.bvh))
         r2.set_shard(rank, world)
@@ -554,7 +556,7 @@ def run_workload(name: str, args, rank: int, world: int, local: int, dev, steps:
                "lit_fraction": lit, "image_crc32": crc, "stats": st}
     torch.cuda.synchronize(dev)
     torch.cuda.set_stream(torch.cuda.default_stream(dev))      # the contexts' streams die with them
-    for rr, _, _ in ctxs:
+    for rr, _, _ in reversed(ctxs):                  # (contexts that share the first one's scene go first)
         rr.close()
     if ls is not None:
         ls.close()

@@ -307,6 +307,11 @@ int rt_scene_layout_resolution(const void* layout, uint64_t bytes, int32_t* widt
 int32_t rt_scene_array_count(const rt_ctx* ctx);
 int rt_scene_array(rt_ctx* ctx, int32_t k, void** dev_ptr, uint64_t* bytes);
 int rt_adopt_scene_from(rt_ctx* dst, rt_ctx* src);
+/* Several contexts of ONE GPU that render the same scene side by side (frames in flight): dst uses src's device arrays
+ * in place - nothing is allocated or copied, and the caches hold one copy of the scene instead of one per context.
+ * src owns the arrays: it must stay alive, and keep its scene, for as long as dst renders from them (rt_upload_scene
+ * or an adoption on dst ends the sharing).  No counterpart in the reference (one scene, one thread). */
+int rt_share_scene_from(rt_ctx* dst, rt_ctx* src);
 
 /* ---- several GPUs of one node, one process (no counterpart in the reference, which is single-threaded) ------------
  * The render loop of raytracer.cpp:109-193 split over n devices: device k renders the 32x32 tiles with

@@ -115,7 +115,7 @@ API_SYMBOLS = ["rt_default_config", "rt_create", "rt_destroy", "rt_set_stream", 
                "rt_assemble_tiles", "rt_synchronize", "rt_last_error", "rt_render_device_noalloc", "rt_noalloc_capacity",
                "rt_alloc_image", "rt_free_image",
                "rt_scene_layout_bytes", "rt_export_scene_layout", "rt_adopt_scene_layout", "rt_scene_layout_resolution",
-               "rt_scene_array_count", "rt_scene_array", "rt_adopt_scene_from",
+               "rt_scene_array_count", "rt_scene_array", "rt_adopt_scene_from", "rt_share_scene_from",
                "rt_multi_create", "rt_multi_destroy", "rt_multi_set_option", "rt_multi_upload", "rt_multi_render", "rt_multi_render_device",
                "rt_multi_synchronize", "rt_multi_image", "rt_multi_context", "rt_multi_uses_rccl", "rt_multi_last_error"]
 HOST_SYMBOLS = ["rt_host_parse_args", "rt_host_parse_scene", "rt_host_load_scene", "rt_host_free_scene",
@@ -168,6 +168,7 @@ def lib():
     L.rt_scene_array_count.argtypes = [C.c_void_p]; L.rt_scene_array_count.restype = C.c_int32
     L.rt_scene_array.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.rt_adopt_scene_from.argtypes = [C.c_void_p, C.c_void_p]
+    L.rt_share_scene_from.argtypes = [C.c_void_p, C.c_void_p]
     L.rt_scene_layout_resolution.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rt_alloc_image.argtypes = [C.c_uint64]; L.rt_alloc_image.restype = C.c_void_p
     L.rt_free_image.argtypes = [C.c_void_p]; L.rt_free_image.restype = None
@@ -536,6 +537,12 @@ class Renderer:
         """The scene of another context of this process, copied device to device (no host work, no build)."""
         self._check(lib().rt_adopt_scene_from(self._ctx, other._ctx))
         self.width, self.height = other.width, other.height
+
+    def share_from(self, other: "Renderer"):
+        """The scene of another context of the same GPU, used in place: `other` owns the arrays and must outlive this use."""
+        self._check(lib().rt_share_scene_from(self._ctx, other._ctx))
+        self.width, self.height = other.width, other.height
+        self._shares = other          # keeps the owner alive
 
     @property
     def local_tiles(self) -> int:

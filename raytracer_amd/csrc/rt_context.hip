@@ -218,6 +218,7 @@ struct rt_ctx {
     int grid_primary = 0, grid_secondary = 0, grid_shadow = 0, grid_shade = 0, grid_shadow_drain = 0;
     bool cull_cones = true;                  // see k_shadow: soft-shadow cones that miss every primitive are not traced
     bool fuse_simple = true;                 // frames without recursion and with hard shadows: trace, shadow and shade in one kernel
+    bool shadow_queue_deep = true;           // ... also for the launch that covers the levels below the first reflection
     int shadow_queue_rcap = 0;               // (tests) entries per region of such a queue instead of the planned number
     bool shadow_queue = true;                // ... and the pairs that do need tracing go through a queue in memory to a launch of their own
     bool trace_masks = false;                // ... and traced sample rays only search what their pair's cone can reach
@@ -256,7 +257,8 @@ struct rt_ctx {
     long long n_textures = 0, n_texels = 0, total_sub_nodes = 0, total_sub_entries = 0, total_wide = 0;
     int file_wide_base = -1;                             // first record of the file-order set's hierarchy in d_sub_wide, or -1
     bool adopted = false;                                // the scene's arrays were received from another context, not uploaded
-    std::vector<DevBuf<unsigned char>> adopted_arrays;   // ... and live here
+    std::vector<DevBuf<unsigned char>> adopted_arrays;   // ... and live here,
+    std::vector<std::pair<const void*, size_t>> shared_arrays;   // or in the context they were shared from (rt_share_scene_from), which owns them
     std::vector<std::pair<const void*, size_t>> export_arrays;   // distinct arrays of the last export, in order
 
     // sharding
@@ -422,6 +424,7 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "cull_cones") == 0) { c->cull_cones = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "fuse_simple") == 0) { c->fuse_simple = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "shadow_queue_rcap") == 0) { c->shadow_queue_rcap = value > 0 ? (int)std::min<long long>(value, 1 << 24) : 0; c->drop_graphs(); return RT_OK; }
+    if (std::strcmp(name, "shadow_queue_deep") == 0) { c->shadow_queue_deep = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "shadow_queue") == 0) { c->shadow_queue = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "trace_masks") == 0) { c->trace_masks = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "cull_umbra") == 0) { c->cull_umbra = value != 0; c->drop_graphs(); return RT_OK; }
@@ -658,7 +661,7 @@ static int upload_scene_impl(rt_ctx* c, const rt_scene* sc) {
     RT_HIP(c, hipStreamSynchronize(s));             // the host vectors above die with this scope
     c->n_textures = sc->n_textures; c->n_texels = (long long)texels.size();
     c->adopted = false; for (auto& b : c->adopted_arrays) b.release();
-    c->adopted_arrays.clear(); c->export_arrays.clear();
+    c->adopted_arrays.clear(); c->export_arrays.clear(); c->shared_arrays.clear();
 
     DevScene& d = c->scene;
     std::memset(&d, 0, sizeof d);
@@ -1098,7 +1101,8 @@ int rt_export_scene_layout(rt_ctx* c, void* layout, uint64_t cap) {
     return RT_OK;
 }
 
-static int adopt_layout_impl(rt_ctx* c, const void* layout, uint64_t bytes) {
+// share: the arrays of the layout, in its order, as they exist in another context of the same device: used in place, nothing is allocated or copied
+static int adopt_layout_impl(rt_ctx* c, const void* layout, uint64_t bytes, const std::vector<std::pair<const void*, size_t>>* share = nullptr) {
     if (!c || !layout) return RT_ERR_ARG;
     SceneLayout L;
     if (bytes < sizeof L) return c->fail(RT_ERR_ARG, "scene layout of %llu bytes, %zu expected", (unsigned long long)bytes, sizeof L);
@@ -1120,10 +1124,16 @@ static int adopt_layout_impl(rt_ctx* c, const void* layout, uint64_t bytes) {
     c->drop_graphs();
     c->have_scene = false; c->have_bvh = false; c->adopted = false;
     for (auto& b : c->adopted_arrays) b.release();
-    c->adopted_arrays.clear(); c->export_arrays.clear();
-    c->adopted_arrays.resize((size_t)L.n_arrays);
-    for (int a = 0; a < L.n_arrays; ++a) RT_HIP(c, c->adopted_arrays[(size_t)a].resize((size_t)L.array_bytes[a]));
-    for (int k = 0; k < L.n_slots; ++k) *slots[(size_t)k].p = L.slot_array[k] >= 0 ? c->adopted_arrays[(size_t)L.slot_array[k]].p : nullptr;
+    c->adopted_arrays.clear(); c->export_arrays.clear(); c->shared_arrays.clear();
+    if (share) {
+        if ((int)share->size() != L.n_arrays) return c->fail(RT_ERR_ARG, "scene layout: %d arrays, %zu offered", L.n_arrays, share->size());
+        c->shared_arrays = *share;
+        for (int k = 0; k < L.n_slots; ++k) *slots[(size_t)k].p = L.slot_array[k] >= 0 ? (unsigned char*)const_cast<void*>(c->shared_arrays[(size_t)L.slot_array[k]].first) : nullptr;
+    } else {
+        c->adopted_arrays.resize((size_t)L.n_arrays);
+        for (int a = 0; a < L.n_arrays; ++a) RT_HIP(c, c->adopted_arrays[(size_t)a].resize((size_t)L.array_bytes[a]));
+        for (int k = 0; k < L.n_slots; ++k) *slots[(size_t)k].p = L.slot_array[k] >= 0 ? c->adopted_arrays[(size_t)L.slot_array[k]].p : nullptr;
+    }
     c->scene = L.scene; c->scene.walk_stats = nullptr;
     c->camera = L.camera; c->np = (int)L.np; c->nc = (int)L.nc; c->ns = (int)L.ns; c->n_lights = L.n_lights;
     c->n_textures = L.n_textures; c->n_texels = L.n_texels; c->total_wide = L.sub_nodes; c->total_sub_nodes = 0; c->total_sub_entries = L.sub_entries;
@@ -1155,13 +1165,14 @@ int rt_scene_layout_resolution(const void* layout, uint64_t bytes, int32_t* widt
 
 int32_t rt_scene_array_count(const rt_ctx* c) {
     if (!c || !c->have_scene) return 0;
-    return (int32_t)(c->adopted ? c->adopted_arrays.size() : c->export_arrays.size());
+    return (int32_t)(!c->adopted ? c->export_arrays.size() : c->shared_arrays.empty() ? c->adopted_arrays.size() : c->shared_arrays.size());
 }
 
 int rt_scene_array(rt_ctx* c, int32_t k, void** dev_ptr, uint64_t* bytes) {
     if (!c || !dev_ptr || !bytes) return RT_ERR_ARG;
     if (k < 0 || k >= rt_scene_array_count(c)) return c->fail(RT_ERR_ARG, "scene array %d of %d (export or adopt a layout first)", k, rt_scene_array_count(c));
-    if (c->adopted) { *dev_ptr = c->adopted_arrays[(size_t)k].p; *bytes = c->adopted_arrays[(size_t)k].n; }
+    if (c->adopted && !c->shared_arrays.empty()) { *dev_ptr = const_cast<void*>(c->shared_arrays[(size_t)k].first); *bytes = c->shared_arrays[(size_t)k].second; }
+    else if (c->adopted) { *dev_ptr = c->adopted_arrays[(size_t)k].p; *bytes = c->adopted_arrays[(size_t)k].n; }
     else { *dev_ptr = const_cast<void*>(c->export_arrays[(size_t)k].first); *bytes = c->export_arrays[(size_t)k].second; }
     return RT_OK;
 }
@@ -1176,6 +1187,16 @@ int rt_adopt_scene_from(rt_ctx* dst, rt_ctx* src) {
         RT_HIP(dst, hipMemcpyAsync(dst->adopted_arrays[a].p, src->export_arrays[a].first, src->export_arrays[a].second, hipMemcpyDefault, dst->stream));
     RT_HIP(dst, hipStreamSynchronize(dst->stream));
     return RT_OK;
+}
+
+int rt_share_scene_from(rt_ctx* dst, rt_ctx* src) {
+    if (!dst || !src || dst == src) return RT_ERR_ARG;
+    if (dst->device != src->device) return dst->fail(RT_ERR_ARG, "rt_share_scene_from: contexts on devices %d and %d (use rt_adopt_scene_from)", dst->device, src->device);
+    std::vector<unsigned char> blob(sizeof(SceneLayout));
+    if (rt_export_scene_layout(src, blob.data(), blob.size()) != RT_OK) return dst->fail(RT_ERR_STATE, "source context: %s", src->err.c_str());
+    const std::vector<std::pair<const void*, size_t>> arrays = src->export_arrays;       // (as the export just listed them)
+    try { return adopt_layout_impl(dst, blob.data(), blob.size(), &arrays); }
+    catch (const std::exception& e) { dst->have_scene = false; return dst->fail(RT_ERR_ARG, "rt_share_scene_from: %s", e.what()); }
 }
 
 int rt_set_shard(rt_ctx* c, int32_t rank, int32_t world) {
@@ -1609,7 +1630,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
                     RT_HIP(c, hipEventRecord(c->ev_join2, c->aux_stream2));
                 }
             }
-            if (L > 0) { tm->begin(ST_SHADOW); tm->launches[ST_SHADOW] += rt_launch_shadow(s, c->scene, f, w, fork1 ? 2 : (split ? 1 : 0), D, g_shadow, g_drain) - 1; tm->end(); }
+            if (L > 0) { tm->begin(ST_SHADOW); tm->launches[ST_SHADOW] += rt_launch_shadow(s, c->scene, f, w, fork1 ? 2 : (split ? 1 : 0), D, g_shadow, (fork1 && !c->shadow_queue_deep) ? 0 : g_drain) - 1; tm->end(); }
             for (int level = D; level >= 0; --level) {
                 // only the shading of the levels whose shadow rays were forked needs those launches; the deeper levels
                 // resolve beside them

@@ -2383,7 +2383,7 @@ int rt_launch_shadow(hipStream_t s, const DevScene& sc, const DevFrame& f, const
     const bool ldsp = !sub && sc.lds_prims != 0;
     if (sub == 2) rt_launch_shadow_part2(s, sc, f, w, lv_begin, lv_end, grid, lds, false, mode, 0, 0);
     else if (sub == 1) rt_launch_shadow_part1(s, sc, f, w, lv_begin, lv_end, grid, lds, false, mode, 0, 0);
-    else if (w.sq && mode != 0) {
+    else if (w.sq && mode != 0 && grid_drain > 0) {
         // (the context provides the queue where it pays: soft shadows of tiny scenes with the cone rules on, sample counts
         // that tile a wavefront).  Launches of one batch may run side by side: each has a queue of its own.
         const int sq_k = lv_begin < RT_SHADOWQ_LAUNCHES - 1 ? lv_begin : RT_SHADOWQ_LAUNCHES - 1;

@@ -102,6 +102,23 @@ def test_adopted_device_scene_renders_the_source_frames(n, flags, textures_dir):
         b.set_shard(rank, 3)
         blk, _ = b.render(cfg); blocks.append(blk.copy())
     assert np.array_equal(api.assemble_tiles_numpy(blocks, src.width, src.height), want)
+    # (3) contexts of one GPU that render side by side use the source's arrays in place (frames in flight): same frames,
+    # from two contexts at once on their own streams, and no device memory beyond the work buffers
+    free0 = torch.cuda.mem_get_info()[0]
+    s1 = api.Renderer(0); s1.share_from(src)
+    s2 = api.Renderer(0); s2.share_from(src)
+    assert sorted(src.scene_arrays()) == sorted(s1.scene_arrays())
+    o1 = torch.empty(s1.out_bytes(), dtype=torch.uint8, device="cuda"); o2 = torch.empty_like(o1)
+    for k in range(3):
+        s1.render_device(cfg, o1.data_ptr()); s2.render_device(cfg, o2.data_ptr())
+    s1.synchronize(); s2.synchronize()
+    assert np.array_equal(o1.cpu().numpy().reshape(want.shape), want) and np.array_equal(o2.cpu().numpy().reshape(want.shape), want)
+    scene_bytes = sum(n for _, n in src.scene_arrays())
+    if scene_bytes > (64 << 20):
+        assert free0 - torch.cuda.mem_get_info()[0] < scene_bytes          # two more contexts, less than one more copy of the scene
+    s1.upload(ls, with_bvh=bool(cfg.bvh))                                  # an upload ends the sharing
+    assert np.array_equal(s1.render(cfg)[0], want)
+    s1.close(); s2.close()
     # a tree cannot be uploaded into an adopted scene; a fresh upload replaces it
     with pytest.raises(api.RtError) as e:
         hb = ls.bvh()
