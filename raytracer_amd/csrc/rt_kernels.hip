@@ -1309,7 +1309,8 @@ DEVI ConeSets cone_sets(const DevScene& sc, bool mb, float time, V3 p, V3 lc, fl
             const float least = na * cos_t - __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - na * na)) * sin_t;    // smallest n.d over the cone
             const float scale = fmaxf(fmaxf(fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fmaxf(fabsf(p.z), 1.0f)), fmaxf(fmaxf(fabsf(w1.x), fabsf(w1.y)), fabsf(w1.z))),
                                       fmaxf(fmaxf(fabsf(w2.y), fabsf(w2.z)), fabsf(w2.w)));
-            ruled_out = least > 0.2f && fmaxf(h, h2) < 1e-4f - 2e-6f * scale;      // 0.001 x 0.2 of head start against the rounding of h
+            // t = h / (n.d) - 0.001 < 0 as long as h < 0.001 x least; half of that against the rounding of h
+            ruled_out = least > 0.02f && fmaxf(h, h2) < 5e-4f * least - 2e-6f * scale;
         }
         if (ruled_out) continue;
         const float4 bs = sc.plane_bound[i];
