@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: pmc_frame.sh <outdir> <workload> <kernel substring> <options> <counters...>   per-dispatch counters of the last frame's matching dispatches
 set -u
-cd "$(dirname "$0")/../.." || exit 1
+cd "$(dirname "$0")/.." || exit 1
 O=$1; WL=$2; K=$3; OPTS=$4; shift 4
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp

@@ -1,6 +1,8 @@
+"""Development aid: the sampling noise behind the seed-mean soft-shadow cases (tests/cases.SEED_MEAN) - PSNR between the
+GPU's mean over seeds, the restatement's mean over seeds and the reference's high-sample golden."""
 import sys, copy, numpy as np
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent.parent
+ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "oracle"))
 import cases
 from raytracer_amd import api

@@ -1,6 +1,10 @@
+"""Development aid: of the (hit, light) pairs of scene.json that the cone rules of k_shadow send to tracing, how many end with
+every sample blocked, some, or none - the pairs a sharper rule could still decide without tracing.  Needs a library
+built with -DRT_SHADOW_HIST (make -C raytracer_amd/csrc B=build_hist OUT=../librt_amd_hist.so KDEFS=-DRT_SHADOW_HIST).
+usage: RT_AMD_LIB=raytracer_amd/librt_amd_hist.so python tools/shadow_pair_hist.py "-r -rd 4 -ss -sss 16" """
 import ctypes as C, sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent.parent
+ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import torch, cases
 from raytracer_amd import api

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: trace_frame.sh <outdir> <workload> <option set>...   per-dispatch kernel times of the last frame under each option set
 set -u
-cd "$(dirname "$0")/../.." || exit 1
+cd "$(dirname "$0")/.." || exit 1
 O=$1; WL=$2; shift 2
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
