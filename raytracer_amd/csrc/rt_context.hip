@@ -221,7 +221,6 @@ struct rt_ctx {
     bool shadow_queue_deep = true;           // ... also for the launch that covers the levels below the first reflection
     int shadow_queue_rcap = 0;               // (tests) entries per region of such a queue instead of the planned number
     bool shadow_queue = true;                // ... and the pairs that do need tracing go through a queue in memory to a launch of their own
-    bool trace_masks = false;                // ... and traced sample rays only search what their pair's cone can reach
     bool cull_umbra = true;                  // ... and pairs whose whole cone of sample rays is certain to be blocked
     bool cull_own = true;                    // ... where a sphere or cube is left out for the rays that leave its own surface outwards
     bool bundle_reflections = true;          // ... as one traced ray with gr_samples hit records (off: gr_samples traced rays)
@@ -426,7 +425,6 @@ int rt_set_option(rt_ctx* c, const char* name, int64_t value) {
     if (std::strcmp(name, "shadow_queue_rcap") == 0) { c->shadow_queue_rcap = value > 0 ? (int)std::min<long long>(value, 1 << 24) : 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "shadow_queue_deep") == 0) { c->shadow_queue_deep = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "shadow_queue") == 0) { c->shadow_queue = value != 0; c->drop_graphs(); return RT_OK; }
-    if (std::strcmp(name, "trace_masks") == 0) { c->trace_masks = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "cull_umbra") == 0) { c->cull_umbra = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "cull_own") == 0) { c->cull_own = value != 0; c->drop_graphs(); return RT_OK; }
     if (std::strcmp(name, "bundle_reflections") == 0) { c->bundle_reflections = value != 0; c->drop_graphs(); return RT_OK; }
@@ -1423,7 +1421,7 @@ static int enqueue_frame(rt_ctx* c, const rt_config* cfg, unsigned char* out_dev
     int fb = cfg->fallback; if (fb == 0) fb = 1;
     f.fallback_full = (fb == 1);
     f.light_radius = cfg->light_radius; f.seed = cfg->seed; f.fast_samples = c->fast_samples ? 1 : 0; f.count_stats = count_stats ? 1 : 0; f.skip_unlit = c->skip_unlit ? 1 : 0;
-    f.cull_cones = c->cull_cones ? 1 : 0; f.cull_own = c->cull_own ? 1 : 0; f.cull_umbra = c->cull_umbra ? 1 : 0; f.trace_masks = c->trace_masks ? 1 : 0;
+    f.cull_cones = c->cull_cones ? 1 : 0; f.cull_own = c->cull_own ? 1 : 0; f.cull_umbra = c->cull_umbra ? 1 : 0;
     f.replicate = (cfg->soft_shadows && c->replicate_reflections) ? 1 : 0;
     // identical reflection rays are traced once and recorded gr_samples times (the packed hit record holds 12-bit copy numbers)
     f.bundle = (f.replicate && !cfg->glossy_reflect && cfg->gr_samples <= 4096 && c->bundle_reflections) ? 1 : 0;

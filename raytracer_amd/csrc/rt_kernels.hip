@@ -1063,71 +1063,6 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_EXTEND_WAVES_SUB : RT_EXTEND_WAV
     }
 }
 
-// Sample rays of a pair whose cone can only reach the primitives in `may` (bits by global id, see cone_sets): the same
-// search as trace<false, 0, FAST> with stop_below = the light sample's distance, leaving out what cannot be hit -
-// primitives outside `may`, and whole subtrees of the first level that hold none of them (sub_held[i]: the primitives in
-// the leaves under node i).  A primitive that cannot be hit reports nothing, so the leaf that ends the reference's walk,
-// and whether its closest distance is below stop_below, are the same.  Returns that decision: blocked.
-template <bool FAST>
-DEVI bool test_prims_of(const DevPrimSet& S, const Ray& r, bool mb, int p0, int pn, int c0, int cn, int s0, int sn, bool leaf_rule, float stop_below, unsigned may, bool& any) {
-    float closest = leaf_rule ? INFINITY : FLT_MAX;
-    for (int i = p0; i < p0 + pn; ++i) {
-        float t;
-        if (!((may >> (f2i(S.planes[3 * i + 2].x) & 31)) & 1u)) continue;
-        if (plane_test<false, FAST>(S.planes + 3 * i, S.edges, nullptr, r, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
-            any = true; closest = t;
-            if (t < stop_below) return true;
-        }
-    }
-    for (int i = c0; i < c0 + cn; ++i) {
-        float t;
-        if (!((may >> (f2i(S.cubes[6 * i + 3].z) & 31)) & 1u)) continue;
-        if (cube_test<false, FAST>(S.cubes + 6 * i, r, mb, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
-            any = true; closest = t;
-            if (t < stop_below) return true;
-        }
-    }
-    for (int i = s0; i < s0 + sn; ++i) {
-        float t;
-        if (!((may >> (f2i(S.spheres[2 * i + 1].w) & 31)) & 1u)) continue;
-        if (sphere_test<false, FAST>(S.spheres + 2 * i, r, mb, false, t, nullptr) && (!leaf_rule || t >= 0.0f) && t < closest) {
-            any = true; closest = t;
-            if (t < stop_below) return true;
-        }
-    }
-    return false;
-}
-
-template <bool FAST>
-DEVI bool blocked_among(const DevScene& sc, const DevFrame& f, const float4* __restrict__ nodes, const int4* __restrict__ leaves, const unsigned* __restrict__ sub_held,
-                        const Ray& r, float stop_below, unsigned may) {
-    const bool mb = f.motion_blur != 0;
-    bool any = false;
-    if (!f.use_bvh) {
-        const DevPrimSet& FS = sc.fileset;
-        return test_prims_of<FAST>(FS, r, mb, 0, FS.n_planes, 0, FS.n_cubes, 0, FS.n_spheres, false, stop_below, may, any);
-    }
-    const float ax = fabsf(r.d.x), ay = fabsf(r.d.y), az = fabsf(r.d.z);
-    const bool fast_ok = ax > 1e-18f && ax < 1e18f && ay > 1e-18f && ay < 1e18f && az > 1e-18f && az < 1e18f;
-    const V3 rcp = mk(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
-    int i = 0;
-    const int n = sc.n_nodes;
-    while (i < n) {
-        const float4 a = nodes[2 * i];
-        if (!(sub_held[i] & may)) { i = f2i(a.w); continue; }
-        const float4 b = nodes[2 * i + 1];
-        if (!slab<FAST>(r, a, b, rcp, fast_ok)) { i = f2i(a.w); continue; }
-        const int leaf = f2i(b.w);
-        ++i;
-        if (leaf >= 0) {
-            const int4 l0 = leaves[2 * leaf], l1 = leaves[2 * leaf + 1];
-            if (test_prims_of<FAST>(sc.leafset, r, mb, l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, true, stop_below, may, any)) return true;
-            if (any) return false;                                       // this leaf's result is what the reference returns
-        }
-    }
-    return false;
-}
-
 // Soft shadows of a scene with a handful of primitives: what the sample rays of a (hit, light) pair can hit, decided
 // once per pair.  The sample rays lie on lines through the hit point p (they start 0.001 along their own direction,
 // raytracer.cpp:549) and aim at points of the ball of radius R around the light (raytracer.cpp:541), so their
@@ -1352,8 +1287,10 @@ DEVI int cone_outcome(const DevScene& sc, const float4* __restrict__ nodes, cons
 // ---------------------------------------------------------------------------------------------------------
 // MODE: 0 = hard shadows, 1 = soft shadows in the reference's arithmetic, 2 = soft shadows on reciprocals (separate
 // kernels: each needs fewer registers than one kernel holding both searches, which decides how many wavefronts fit)
-template <int SUB, bool LDSP, int MODE>
-__global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAVES) void k_shadow(DevScene sc_arg, DevFrame f, DevWork w, int lv_begin, int lv_end, int phase, int sq_k) {
+// PHASE (see `phase` below): compiled apart, so that each launch carries the registers of its own part only
+template <int SUB, bool LDSP, int MODE, int PHASE>
+__global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : (PHASE == 1 ? RT_SHADOW_WAVES - 1 : RT_SHADOW_WAVES)) void k_shadow(DevScene sc_arg, DevFrame f, DevWork w, int lv_begin, int lv_end, int sq_k) {
+    constexpr int phase = PHASE;
     extern __shared__ float4 s_mem[];
     DevScene sc = sc_arg;
     float4* s_nodes = s_mem;
@@ -1410,26 +1347,6 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
 
     // the cone test loops over every primitive: for scenes with a handful of them
     const bool cull = f.cull_cones && sc.fileset.n_planes + sc.fileset.n_cubes + sc.fileset.n_spheres <= 8;
-    // ... whose first level is a handful of nodes: which primitives (bits by global id) the leaves under each node hold
-    constexpr int MAX_HELD = 64;
-    __shared__ unsigned s_sub_held[SUB || MODE == 0 ? 1 : MAX_HELD];
-    const bool masks = !SUB && MODE != 0 && cull && f.trace_masks && (!f.use_bvh || sc.n_nodes <= MAX_HELD);
-    if (masks && f.use_bvh) {
-        for (int i = threadIdx.x; i < sc.n_nodes; i += blockDim.x) {
-            unsigned held = 0u;
-            const int end = f2i(s_nodes[2 * i].w);
-            for (int k = i; k < end && k < sc.n_nodes; ++k) {
-                const int leaf = f2i(s_nodes[2 * k + 1].w);
-                if (leaf < 0) continue;
-                const int4 l0 = s_leaves[2 * leaf], l1 = s_leaves[2 * leaf + 1];
-                for (int q = l0.x; q < l0.x + l0.y; ++q) held |= 1u << (f2i(sc.leafset.planes[3 * q + 2].x) & 31);
-                for (int q = l0.z; q < l0.z + l0.w; ++q) held |= 1u << (f2i(sc.leafset.cubes[6 * q + 3].z) & 31);
-                for (int q = l1.x; q < l1.x + l1.y; ++q) held |= 1u << (f2i(sc.leafset.spheres[2 * q + 1].w) & 31);
-            }
-            s_sub_held[i] = held;
-        }
-        __syncthreads();
-    }
     int* __restrict__ out = (int*)w.shadow;
     unsigned long long n_rays = 0;
     const float4 light0 = sc.lights[0];                                 // count > 0 implies a light; the usual scene has one
@@ -1459,13 +1376,11 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         sr.d = ld;
         return lightDist;
     };
-    // may: the pair's cone can only reach these primitives (tiny scenes with the cone rules on), 0 = no such knowledge
-    auto sample_unblocked = [&](int node, bool have_path, uint32_t path, int cp, int l, int j, const float4 a, const float4 lt, unsigned may) __attribute__((always_inline)) -> bool {
+    auto sample_unblocked = [&](int node, bool have_path, uint32_t path, int cp, int l, int j, const float4 a, const float4 lt) __attribute__((always_inline)) -> bool {
         Ray sr;
         Best best; best.t = 0.0f; best.cls = 0; best.idx = 0; best.fileset = 0;
         const float lightDist = make_sample_ray(node, have_path, path, cp, l, j, a, lt, sr);
         if (MODE == 0) return !trace<true, SUB>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best);
-        if (!SUB && MODE != 0 && may != 0u) return !blocked_among<FAST>(sc, f, s_nodes, s_leaves, s_sub_held, sr, lightDist, may);
         // only "closest reported distance < lightDist" is asked for (raytracer.cpp:564)
         const bool hit = trace<false, SUB, FAST>(sc, f, s_nodes, s_leaves, s_stack, sr, false, best, lightDist);
         return !(hit && best.t < lightDist);
@@ -1483,7 +1398,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
     int seg = 0;
     if (grouped && phase == 2) {
         // the queued pairs, pairs_per_pass at a time: SS neighbouring lanes per pair, counted with a ballot.  An entry
-        // holds what a sample ray needs - (index into shadow[], copy | may << 16, path id, hit time), (hit point) - and the
+        // holds what a sample ray needs - (index into shadow[], copy, path id, hit time), (hit point) - and the
         // next chunk's entries are requested before this chunk's rays are traced.
         const int j = (int)(threadIdx.x & (unsigned)(SS - 1));
         auto fetch = [&](int g, int4& e0, float4& e1) -> bool {
@@ -1503,7 +1418,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
             if (active) {
                 const int l = (L == 1) ? 0 : c0.x % L;
                 ++n_rays;
-                unblocked = sample_unblocked(0, true, (uint32_t)c0.z, c0.y & 0xffff, l, j, make_float4(c1.x, c1.y, c1.z, i2f(c0.w)), (L == 1) ? light0 : sc.lights[l], (unsigned)c0.y >> 16);
+                unblocked = sample_unblocked(0, true, (uint32_t)c0.z, c0.y, l, j, make_float4(c1.x, c1.y, c1.z, i2f(c0.w)), (L == 1) ? light0 : sc.lights[l]);
             }
             const unsigned long long m = __ballot(active && unblocked);
             if (active && j == 0) {
@@ -1546,7 +1461,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         NodeAt cur = locate((int)blockIdx.x, a, b);
         for (int g = (int)blockIdx.x; g < n_chunks; g += (int)gridDim.x) {
             const NodeAt nxt = locate(g + (int)gridDim.x, a_next, b_next);
-            int n_push = 0; unsigned may16 = 0u;
+            int n_push = 0;
             // a node of a level with several slots per node has either one copy or all of them (top bit of the id word)
             const int ncp = (cur.valid && cur.mul > 1 && f2i(b.w) < 0) ? cur.mul : 1;
             const float4 lt = (L == 1) ? light0 : sc.lights[cur.l];
@@ -1557,7 +1472,6 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                     const ConeSets cs = cone_sets(sc, f.motion_blur != 0, a.w, mk(a.x, a.y, a.z), mk(lt.x, lt.y, lt.z), f.light_radius,
                                                   f.cull_own ? (f2i(b.w) & 0x7fffffff) : -1, mk(b.x, b.y, b.z), f.cull_umbra != 0);
                     what = cone_outcome(sc, s_nodes, s_leaves, f.use_bvh != 0, cs);
-                    if (masks) may16 = cs.may & 0xffffu;
                 }
                 if (what == CONE_TRACE) n_push = ncp;
                 else for (int cp = 0; cp < ncp; ++cp) out[cur.item0 + cp * cur.cstep] = what == CONE_NONE ? SS : 0;
@@ -1576,11 +1490,11 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                     for (int cp = 0; cp < n_push; ++cp) {
                         if (at + cp < w.sq_rcap) {
                             int4* __restrict__ e = qbase + 2 * (size_t)(at + cp);
-                            e[0] = make_int4(cur.item0 + cp * cur.cstep, cp | (int)(may16 << 16), path, f2i(a.w));
+                            e[0] = make_int4(cur.item0 + cp * cur.cstep, cp, path, f2i(a.w));
                             *(float4*)(e + 1) = make_float4(a.x, a.y, a.z, 0.0f);
                         } else {
                             int cnt = 0;
-                            for (int j = 0; j < SS; ++j) { ++n_rays; cnt += sample_unblocked(cur.node, true, (uint32_t)path, cp, cur.l, j, a, lt, may16) ? 1 : 0; }
+                            for (int j = 0; j < SS; ++j) { ++n_rays; cnt += sample_unblocked(cur.node, true, (uint32_t)path, cp, cur.l, j, a, lt) ? 1 : 0; }
                             out[cur.item0 + cp * cur.cstep] = cnt;
                         }
                     }
@@ -1602,7 +1516,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         // (scenes with second-level hierarchies collect more pairs before they trace: see the drain below)
         constexpr int QCAP = 2 * RT_BLOCK;
         __shared__ int s_q[QCAP], s_qnode[QCAP];                      // queued pairs: index into `out`; node
-        __shared__ unsigned s_qcp[QCAP];                              // ... which of the node's copies (< 4096) | what its sample rays may hit << 16
+        __shared__ unsigned short s_qcp[QCAP];                        // ... and which of the node's copies (< 4096)
         __shared__ int s_qn, s_next;
         __shared__ unsigned s_qcnt[SUB ? QCAP / 2 : 1];              // the drain's unblocked samples per queued pair, 16 bits each
         if (threadIdx.x == 0) { s_qn = 0; s_next = 0; }
@@ -1646,7 +1560,6 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                                                       f.cull_own ? (f2i(b.w) & 0x7fffffff) : -1, mk(b.x, b.y, b.z), f.cull_umbra != 0);
                         const int what = cone_outcome(sc, s_nodes, s_leaves, f.use_bvh != 0, cs);
                         if (what == CONE_TRACE) queue = true; else out[item] = what == CONE_NONE ? SS : 0;
-                        if (masks) qcp |= (int)((cs.may & 0xffffu) << 16);
                     }
                     else queue = true;
                 }
@@ -1657,7 +1570,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                 int base = 0;
                 if (__lane_id() == 0 && m) base = atomicAdd(&s_qn, __popcll(m));
                 base = __shfl(base, 0, 64);
-                if (queue) { const int at = base + __popcll(m & ((1ull << __lane_id()) - 1ull)); s_q[at] = item; s_qnode[at] = qnode; s_qcp[at] = (unsigned)qcp; }
+                if (queue) { const int at = base + __popcll(m & ((1ull << __lane_id()) - 1ull)); s_q[at] = item; s_qnode[at] = qnode; s_qcp[at] = (unsigned short)qcp; }
             }
             __syncthreads();
             int qn = s_qn;
@@ -1832,10 +1745,10 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                 if (active) {
                     it = s_q[first + k];
                     const int node = s_qnode[first + k];
-                    const unsigned cpm = s_qcp[first + k];
+                    const int cp = (int)(s_qcp[first + k] & 0xffffu);
                     const int l = (L == 1) ? 0 : it % L;
                     ++n_rays;
-                    unblocked = sample_unblocked(node, false, 0u, (int)(cpm & 0xffffu), l, j, w.n_a[node], (L == 1) ? light0 : sc.lights[l], cpm >> 16);
+                    unblocked = sample_unblocked(node, false, 0u, cp, l, j, w.n_a[node], (L == 1) ? light0 : sc.lights[l]);
                 }
                 const unsigned long long m = __ballot(active && unblocked);
                 if (active && j == 0) {
@@ -1844,9 +1757,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
                     out[it] = __popcll(grp);
 #ifdef RT_SHADOW_HIST
                     // development: how many traced pairs end fully blocked / partly / fully unblocked (level 0; deeper levels)
-                    { const int cnt = __popcll(grp); atomicAdd(&w.stats[RT_S_WALK + (lv_begin ? 20 : 16) + (cnt == 0 ? 0 : cnt == SS ? 2 : 1)], 1ull);
-                      const int may3 = (int)(s_qcp[first + k] >> 16) & 7;
-                      if (cnt == SS) atomicAdd(&w.stats[RT_S_WALK + may3], 1ull); else if (cnt == 0) atomicAdd(&w.stats[RT_S_WALK + 8 + may3], 1ull); else atomicAdd(&w.stats[RT_S_WALK + 24 + may3], 1ull); }
+                    { const int cnt = __popcll(grp); atomicAdd(&w.stats[RT_S_WALK + (lv_begin ? 20 : 16) + (cnt == 0 ? 0 : cnt == SS ? 2 : 1)], 1ull); }
 #endif
                 }
                 qn = first;
@@ -1875,7 +1786,7 @@ __global__ __launch_bounds__(RT_BLOCK, SUB ? RT_SHADOW_WAVES_SUB : RT_SHADOW_WAV
         const float4 lt = (L == 1) ? light0 : sc.lights[l];
         if (!faces_light(a, b, lt)) continue;                            // the host zeroed the counts for this layout
         ++n_rays;
-        if (sample_unblocked(node, false, 0u, cp, l, j, a, lt, 0u)) atomicAdd(&out[(__builtin_amdgcn_readfirstlane(s_sbase[seg]) + cp * __builtin_amdgcn_readfirstlane(s_cstride[seg]) + node_local) * L + l], 1);
+        if (sample_unblocked(node, false, 0u, cp, l, j, a, lt)) atomicAdd(&out[(__builtin_amdgcn_readfirstlane(s_sbase[seg]) + cp * __builtin_amdgcn_readfirstlane(s_cstride[seg]) + node_local) * L + l], 1);
     }
     if (f.count_stats) block_stat_add(&w.stats[RT_S_SHADOW], n_rays, s_tmp);
 }
@@ -2319,12 +2230,18 @@ void RT_CAT(rt_launch_fused_part, RT_PART_SUB)(hipStream_t s, const DevScene& sc
 #if RT_PART_KIND == 3
 void RT_CAT(rt_launch_shadow_part, RT_PART_SUB)(hipStream_t s, const DevScene& sc, const DevFrame& f, const DevWork& w, int lv_begin, int lv_end, int grid, size_t lds, bool ldsp, int mode, int phase, int sq_k) {
     constexpr int SUB = RT_PART_SUB;
+#define RT_SHADOW_LAUNCH_P(LDSP, MODE, PHASE) hipLaunchKernelGGL((k_shadow<SUB, LDSP, MODE, PHASE>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end, sq_k)
+    // (the phases of the queue of pairs exist for soft shadows of scenes without second-level hierarchies only)
+#define RT_SHADOW_LAUNCH_M(LDSP, MODE) \
+    do { if (SUB == 0 && MODE != 0 && phase == 1) RT_SHADOW_LAUNCH_P(LDSP, MODE, (SUB == 0 && MODE != 0 ? 1 : 0)); \
+         else if (SUB == 0 && MODE != 0 && phase == 2) RT_SHADOW_LAUNCH_P(LDSP, MODE, (SUB == 0 && MODE != 0 ? 2 : 0)); \
+         else RT_SHADOW_LAUNCH_P(LDSP, MODE, 0); } while (0)
 #define RT_SHADOW_LAUNCH(LDSP) \
-    do { if (mode == 2) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 2>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end, phase, sq_k); \
-         else if (mode == 1) hipLaunchKernelGGL((k_shadow<SUB, LDSP, 1>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end, phase, sq_k); \
-         else hipLaunchKernelGGL((k_shadow<SUB, LDSP, 0>), dim3(grid), dim3(RT_BLOCK), lds, s, sc, f, w, lv_begin, lv_end, phase, sq_k); } while (0)
+    do { if (mode == 2) RT_SHADOW_LAUNCH_M(LDSP, 2); else if (mode == 1) RT_SHADOW_LAUNCH_M(LDSP, 1); else RT_SHADOW_LAUNCH_M(LDSP, 0); } while (0)
     if (SUB == 0 && ldsp) RT_SHADOW_LAUNCH((SUB == 0));
     else RT_SHADOW_LAUNCH(false);
+#undef RT_SHADOW_LAUNCH_P
+#undef RT_SHADOW_LAUNCH_M
 #undef RT_SHADOW_LAUNCH
 }
 #endif

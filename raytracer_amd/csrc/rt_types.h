@@ -102,7 +102,6 @@ struct DevFrame {
     int cull_cones;                // soft shadows of tiny scenes: (hit, light) pairs whose whole cone of sample rays misses everything are not traced
     int cull_own;                  // ... and a convex primitive (sphere, cube) is not searched for the sample rays that leave its own surface outwards
     int cull_umbra;                // ... and pairs whose every sample ray is certain to be blocked by one convex primitive (count 0) are not traced either
-    int trace_masks;               // ... and the sample rays that are traced only search what their pair's cone can reach
     int bundle;                    // ... as ONE traced ray whose node has gr_samples copies (replicate, no glossy perturbation)
     int count_stats;               // kernels add their ray counts to DevWork::stats (one atomic per workgroup and counter)
     // sharding
@@ -157,7 +156,7 @@ struct DevWork {
     // Soft shadows of tiny scenes: (hit, light) pairs whose sample rays must be traced, queued by the launch that
     // classifies the pairs and traced by a second launch that deals them out evenly (see k_shadow).  One queue per
     // shadow launch of a batch (RT_SHADOWQ_LAUNCHES), each cut into `regions` parts of sq_rcap entries with their own
-    // counters: entry = two words, (index into shadow[], copy | what the sample rays may hit << 16, path id, hit time) and
+    // counters: entry = two words, (index into shadow[], copy, path id, hit time) and
     // (hit point, 0).  NULL / 0: pairs are traced by the workgroup that met them.
     int4* sq; int sq_rcap;
 };
