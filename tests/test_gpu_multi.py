@@ -116,6 +116,9 @@ def test_adopted_device_scene_renders_the_source_frames(n, flags, textures_dir):
     scene_bytes = sum(n for _, n in src.scene_arrays())
     if scene_bytes > (64 << 20):
         assert free0 - torch.cuda.mem_get_info()[0] < scene_bytes          # two more contexts, less than one more copy of the scene
+    s3 = api.Renderer(0); s3.share_from(a)                                 # ... also from a context that itself adopted the scene (a rank's first context)
+    assert np.array_equal(s3.render(cfg)[0], want)
+    s3.close()
     s1.upload(ls, with_bvh=bool(cfg.bvh))                                  # an upload ends the sharing
     assert np.array_equal(s1.render(cfg)[0], want)
     s1.close(); s2.close()
