@@ -260,7 +260,16 @@ def roofline(st, workload: str, small_scene: bool) -> dict:
     out = {"kernel": dom, "avg_launch_ms": d["avg_launch_ms"], "traffic": traffic, "counters_from": ctr_origin, "stale": bool(ctr_origin.get("stale")), "frame_valu_busy_ms": frame_busy_s * 1e3 if frame_busy_s else None,
            "traffic_ratio": (traffic / d["bytes_per_launch"]) if (traffic and d["bytes_per_launch"]) else None,
            "hbm_algorithmic": alg, "l2_hit_rate": d.get("l2_hit_rate"), "by_kernel": kernels}
-    if small_scene and "valu_issue_frac" in d:
+    if small_scene and dom == "k_shade" and not ctr_origin.get("stale"):
+        # the pass over the hit tree: records, counts and colours streamed once, a handful of dependent loads per hit, little arithmetic
+        out.update(bound="hbm", achieved=d["GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=d["GBps"] / HBM_PEAK_GBS,
+                   hbm_measured_GBps=d.get("hbm_GBps"), valu_busy_frac=d.get("valu_busy_frac"), valu_issue_frac=d.get("valu_issue_frac"),
+                   note="achieved = the prescribed algorithmic bytes of the launch (144 B per shaded hit) / launch duration measured live; "
+                        "traffic = HBM bytes per launch from the committed counter pass (FETCH_SIZE x2 + WRITE_SIZE; fewer than the "
+                        "prescribed bytes: records are 48 B and stay in the memory-side cache between the kernels), hbm_measured_GBps = "
+                        "traffic / duration.  The pass waits for its dependent loads (hit record -> link -> child colour): "
+                        "valu_busy_frac says how little of it is arithmetic")
+    elif small_scene and "valu_issue_frac" in d:
         out.update(bound="valu", achieved=d["valu_TFLOPs_equiv"], peak=VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=d["valu_issue_frac"],
                    valu_busy_frac=d.get("valu_busy_frac"),
                    note="a handful of primitives: nodes, primitive records and materials are served from LDS, HBM carries only the hit tree "

@@ -21,3 +21,5 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_L
 timeout -s KILL 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d "$OUT/pmc_l2" -- python3 bench.py $ARGS > "$OUT/pmc_l2.log" 2>&1 || { echo "l2 pass failed"; tail -5 "$OUT/pmc_l2.log"; exit 1; }
 { echo "library options during profiling: $RT_BENCH_OPTS   bench args: $ARGS"; python3 tools/summarize_profile.py "$OUT" "$WL"; } > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
+# the raw per-dispatch tables are tens of megabytes per workload; what is kept is the summary, the per-kernel statistics and counters.json
+find "$OUT" -name "*counter_collection.csv" -delete; find "$OUT" -name "*kernel_trace.csv" -delete
