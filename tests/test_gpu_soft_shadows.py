@@ -377,3 +377,25 @@ def test_full_shadow_rule_saves_most_of_the_reference_scene_s_shadow_rays(textur
         traced[umbra] = st.shadow_rays
     ls.close()
     assert traced[1] < 0.6 * traced[0]
+
+
+@pytest.mark.parametrize("scene,flags", [("ref", ["-r", "-rd", "4", "-ss", "-sss", "16"]), ("glass_tex", ["-t", "-rd", "3", "-ss", "-sss", "4", "-grs", "8"]),
+                                         ("mirror", ["-r", "-rd", "3", "-ss", "-sss", "4", "-grs", "3"])])
+def test_shading_copies_a_lane_per_node_or_a_lane_per_slot_gives_the_same_frame(scene, flags, textures_dir):
+    """Levels whose nodes stand for gr_samples copies (the first reflection under soft shadows, and everything below it)
+    are shaded a lane per slot while the level fits one round of the launch, a lane per node walking its copies
+    otherwise; the choice depends on the launch's size and must not show.  grid_shade = 1: every level with a lane per
+    node (and one workgroup for the whole level); 65536: a lane per slot wherever a level has copies; also a
+    gr_samples that is not a power of two (the slot-to-copy division) and one above four (copies in several groups)."""
+    cfg, _ = api.parse_args(flags); cfg.seed = 11
+    ls = api.LoadedScene(cases.SCENES[scene](), cfg, textures_dir)
+    base = None
+    for grid in (0, 1, 7, 65536):
+        r = api.Renderer(0); r.set_option("grid_shade", grid); r.upload(ls, with_bvh=True)
+        img, st = r.render(cfg); r.close()
+        if base is None:
+            base = (img, st); assert img.max() > 0 and st.reflection_rays > 0
+            continue
+        assert np.array_equal(img, base[0]), f"grid_shade {grid}: {(img != base[0]).any(axis=2).sum()} pixels differ"
+        assert st.nodes_shaded == base[1].nodes_shaded
+    ls.close()
