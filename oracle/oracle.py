@@ -60,12 +60,13 @@ def parse_args(flags: list[str]) -> OrcConfig:
     return cfg
 
 
-def render(scene_text: str, flags: list[str], textures_dir: str | None = None, rand_seed: int = 1, window=None, stride=(1, 1)):
+def render(scene_text, flags: list[str], textures_dir: str | None = None, rand_seed: int = 1, window=None, stride=(1, 1), res=None):
     """Returns (image int32 [H,W,3], OrcStats). rand_seed=1 is the state of a process that never called srand.
+    scene_text: str, or - for scenes of gigabytes - the encoded bytes together with res = (width, height).
     window = (x0, y0, x1, y1): render only those pixels (exact for deterministic flag sets), the rest stays 0;
     stride = (sx, sy): of those, only every sx-th column and sy-th row counted from the window's corner."""
     from ref_runner import get_resolution  # same directory
-    w, h = get_resolution(scene_text)
+    w, h = res if res is not None else get_resolution(scene_text)
     cfg = parse_args(flags)
     out = np.zeros(w * h * 3, dtype=np.int32)
     W, H = C.c_int(), C.c_int()
@@ -75,7 +76,7 @@ def render(scene_text: str, flags: list[str], textures_dir: str | None = None, r
         lib().orc_set_window(*[int(v) for v in window])
     else:
         lib().orc_set_window(0, 0, 1 << 30, 1 << 30)
-    rc = lib().orc_render(scene_text.encode(), textures_dir.encode() if textures_dir else None, C.byref(cfg),
+    rc = lib().orc_render(scene_text if isinstance(scene_text, bytes) else scene_text.encode(), textures_dir.encode() if textures_dir else None, C.byref(cfg),
                           rand_seed, out.ctypes.data_as(C.POINTER(C.c_int)), out.size, C.byref(W), C.byref(H),
                           C.byref(st))
     if rc != 0:

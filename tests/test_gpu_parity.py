@@ -467,6 +467,30 @@ def test_million_primitive_frame_matches_the_oracle_on_a_pixel_grid():
     ls.close()
 
 
+def test_ten_million_primitive_frame_matches_the_oracle_on_a_pixel_grid():
+    """The largest configuration's scene at its own size: 10^7 random primitives (seed 43) at 3840x2160, under the
+    deterministic flag sets the CPU restatement can be compared on bit for bit (the configuration's own effects draw random
+    samples): plain, with two levels of mirror reflection, and -u.  Every 80th pixel of every 80th row of the restatement's
+    frames (every 240th for -u, where each ray meets all 10^7 primitives) is committed as a fixture
+    (tests/golden/make_windows_10m.py).  A leaf of the reference's depth-8 tree holds about 39 000 primitives here
+    (bvh.cpp:65-95 tests them one by one)."""
+    grid = np.load(cases.GOLDEN / "windows_10m.npz")
+    n, res = 10_000_000, (3840, 2160)
+    ls = api.ArrayScene(sg.random_prims(n, 43), res)
+    for flags, tag, stride in (([], "bvh", 80), (["-r", "-rd", "2", "-grs", "1"], "refl", 80), (["-u"], "u", 240)):
+        cfg, _ = api.parse_args(flags)
+        r = api.Renderer(0); r.upload(ls, with_bvh=bool(cfg.bvh))
+        img, st = r.render(cfg); r.close()
+        assert st.primary_rays == res[0] * res[1]
+        ref = grid[f"grid_{tag}"]
+        got = img[stride // 2::stride, stride // 2::stride].astype(np.int32)
+        assert got.shape == ref.shape and len(np.unique(ref.reshape(-1, 3), axis=0)) > (100 if stride == 80 else 2)
+        assert np.array_equal(got, ref), f"{flags}: {(got != ref).any(axis=2).sum()} of {ref.shape[0] * ref.shape[1]} sampled pixels differ"
+        if tag == "refl":
+            assert st.reflection_rays > 0
+    ls.close()
+
+
 @pytest.mark.parametrize("flags", [[], ["-u"], ["-rd", "2", "-grs", "1"]])
 def test_second_level_hierarchy_changes_no_pixel_at_a_million_primitives(flags):
     """second_level_min_group on / off at 10^6 primitives on a 160x90 film: the plain search tests the thousands of
