@@ -42,8 +42,11 @@ def _rows(t):
 
 def scene_bytes(n, seed, res):
     t = sg.random_prims(n, seed)
-    with Pool(7) as pool:
-        parts = pool.map(_rows, np.array_split(t, max(7, n // 100_000)))
+    if n < 200_000:
+        parts = [_rows(t)]
+    else:
+        with Pool(7) as pool:
+            parts = pool.map(_rows, np.array_split(t, max(7, n // 100_000)))
     head = json.dumps({"cameras": [sg.camera(res=res)], "point_lights": [sg.light(sg.REF_LIGHT, 1000.0)]})[1:-1]
     ground = json.dumps([sg.ground(50.0, 0.0, sg.material(sg.GROUND_DIFFUSE))])
     txt = b"".join([b'{"properties": {', head.encode(), b', "spheres": [', b", ".join(p[0] for p in parts if p[0]),

@@ -143,3 +143,21 @@ def test_seeded_fixtures_are_what_the_restatement_renders(textures_dir):
     assert np.array_equal(var, seeded["mirror_var"])
     mask = (direct_var == 0) & (var > 0)
     assert mask.sum() >= 100                               # pixels that see a penumbra only through the reflection
+
+
+def test_row_by_row_scene_text_of_the_large_fixtures_is_the_generator_s_scene():
+    """tests/golden/make_windows_10m.py writes the scene text of 10^7 primitives row by row instead of through
+    scenegen.random_scene (ten million dicts): for a small population both texts hold the same numbers, and the
+    restatement renders the same frame from either."""
+    import importlib.util
+    import json
+    from raytracer_amd import scenegen as sg
+    spec = importlib.util.spec_from_file_location("make_windows_10m", cases.GOLDEN / "make_windows_10m.py")
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    res = (64, 36)
+    text = sg.random_scene(300, 43, res)
+    rows = mod.scene_bytes(300, 43, res)
+    assert json.loads(rows) == json.loads(text)
+    a, _ = oracle.render(text, [])
+    b, _ = oracle.render(rows, [], res=res)
+    assert np.array_equal(a, b) and a.max() > 0
